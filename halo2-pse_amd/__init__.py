@@ -1,0 +1,308 @@
+"""halo2_pse_amd -- thin ctypes plumbing over libhalo2hip.so (include/halo2hip.h).
+
+The product is the C-ABI library (HIP kernels for gfx950 + C++ host code); the C++ mirror of
+the reference's Rust interface lives in host/halo2hip.hpp.  This module only exists so that
+tests/, bench.py and __graft_entry__.py can drive the C ABI from Python; names follow the
+reference (halo2_proofs::arithmetic::{best_multiexp, best_fft}, poly::EvaluationDomain,
+poly::kzg::ParamsKZG).  There is no CPU fallback here: if the library or the GPU is
+missing, calls raise.
+
+Arrays: numpy uint64 -- Fr elements (n,4), G1Affine (n,8), G1 Jacobian (12,): 4 x u64 LE limbs,
+Montgomery form (halo2curves' in-memory / RawBytes layout).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhalo2hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "halo2hip.h")
+
+_lib = None
+
+
+class H2HipError(RuntimeError):
+    pass
+
+
+def build(force=False, jobs=4):
+    """compile libhalo2hip.so in-tree (hipcc --offload-arch=gfx950)"""
+    args = ["make", "-C", _HERE, "-j%d" % jobs]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise H2HipError("libhalo2hip.so is not built (run __graft_entry__.build()); no CPU fallback exists")
+        # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64; two HIP
+        # runtimes in one process cannot both open the GPU.  Import torch first so that this
+        # library's NEEDED libamdhip64.so.7 binds to the runtime torch already loaded (same
+        # SONAME).  A pure C++/Rust consumer gets /opt/rocm's runtime through the RUNPATH.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = ctypes.CDLL(LIB_PATH)
+        L.h2hip_last_error.restype = ctypes.c_char_p
+        L.h2hip_version.restype = ctypes.c_char_p
+        L.h2hip_get_msm_window.restype = ctypes.c_uint32
+        L.h2hip_get_msm_window.argtypes = [ctypes.c_size_t]
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise H2HipError("%s failed (rc=%d): %s" % (what, rc, lib().h2hip_last_error().decode()))
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _u64(a, cols=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if cols is not None and (a.ndim != 2 or a.shape[1] != cols):
+        raise ValueError("expected shape (n,%d), got %s" % (cols, a.shape))
+    return a
+
+
+def _fe(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(4)
+    return a
+
+
+def init(device=None):
+    if device is None:
+        _check(lib().h2hip_init(None, 0), "h2hip_init")
+    else:
+        ids = (ctypes.c_int * 1)(int(device))
+        _check(lib().h2hip_init(ids, 1), "h2hip_init")
+
+
+def shutdown():
+    lib().h2hip_shutdown()
+
+
+def device_count():
+    return int(lib().h2hip_device_count())
+
+
+def version():
+    return lib().h2hip_version().decode()
+
+
+# ------------------------------------------------------------------ arithmetic.rs
+def best_multiexp(coeffs, bases):
+    """halo2_proofs::arithmetic::best_multiexp (arithmetic.rs:132-159) for C = bn256::G1Affine.
+    Returns the Jacobian result (12,) uint64."""
+    coeffs, bases = _u64(coeffs, 4), _u64(bases, 8)
+    assert coeffs.shape[0] == bases.shape[0]  # assert_eq!(coeffs.len(), bases.len()), arithmetic.rs:133
+    out = np.zeros(12, dtype=np.uint64)
+    _check(lib().h2hip_msm_bn254(_p(coeffs), _p(bases), ctypes.c_size_t(coeffs.shape[0]), _p(out)), "h2hip_msm_bn254")
+    return out
+
+
+def best_fft(a, omega, log_n):
+    """halo2_proofs::arithmetic::best_fft (arithmetic.rs:171-234) for G = bn256::Fr; in place on `a`."""
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    assert a.shape == (1 << log_n, 4)  # assert_eq!(n, 1 << log_n), arithmetic.rs:184
+    _check(lib().h2hip_ntt_bn254_fr(_p(a), _p(_fe(omega)), ctypes.c_uint32(log_n)), "h2hip_ntt_bn254_fr")
+
+
+def g1_to_affine(xyz):
+    xyz = np.ascontiguousarray(xyz, dtype=np.uint64).reshape(12)
+    out = np.zeros(8, dtype=np.uint64)
+    _check(lib().h2hip_g1_to_affine(_p(xyz), _p(out)), "h2hip_g1_to_affine")
+    return out
+
+
+def g1_fold(partials):
+    partials = np.ascontiguousarray(partials, dtype=np.uint64).reshape(-1, 12)
+    out = np.zeros(12, dtype=np.uint64)
+    _check(lib().h2hip_g1_fold(_p(partials), ctypes.c_size_t(partials.shape[0]), _p(out)), "h2hip_g1_fold")
+    return out
+
+
+def bases_pin(bases):
+    assert bases.dtype == np.uint64 and bases.flags["C_CONTIGUOUS"]
+    _check(lib().h2hip_bases_pin(_p(bases), ctypes.c_size_t(bases.shape[0])), "h2hip_bases_pin")
+
+
+def bases_unpin(bases):
+    _check(lib().h2hip_bases_unpin(_p(bases)), "h2hip_bases_unpin")
+
+
+# ------------------------------------------------------------------ poly/domain.rs
+class EvaluationDomain:
+    """poly::EvaluationDomain<Fr> (poly/domain.rs:18-34): holds the constants `new` computes
+    (:39-142, supplied by the caller -- field inversions are not on the accelerated path) and
+    routes the conversions through the fused device entry points."""
+
+    FIELDS = ("omega", "omega_inv", "extended_omega", "extended_omega_inv", "g_coset", "g_coset_inv",
+              "ifft_divisor", "extended_ifft_divisor")
+
+    def __init__(self, k, extended_k, quotient_poly_degree, **consts):
+        self.k, self.extended_k, self.quotient_poly_degree = int(k), int(extended_k), int(quotient_poly_degree)
+        self.n = 1 << self.k
+        for f in self.FIELDS:
+            setattr(self, f, _fe(consts[f]))
+
+    def extended_len(self):
+        return 1 << self.extended_k
+
+    def lagrange_to_coeff(self, a):
+        """poly/domain.rs:226-236"""
+        a = _u64(a, 4).copy()
+        assert a.shape[0] == 1 << self.k
+        _check(lib().h2hip_ifft_bn254_fr(_p(a), _p(self.omega_inv), ctypes.c_uint32(self.k), _p(self.ifft_divisor)),
+               "h2hip_ifft_bn254_fr")
+        return a
+
+    def coeff_to_extended(self, a):
+        """poly/domain.rs:240-254"""
+        a = _u64(a, 4)
+        assert a.shape[0] == 1 << self.k
+        out = np.zeros((self.extended_len(), 4), dtype=np.uint64)
+        _check(lib().h2hip_coeff_to_extended_bn254_fr(_p(a), ctypes.c_uint32(self.k), _p(out), ctypes.c_uint32(self.extended_k),
+                                                      _p(self.extended_omega), _p(self.g_coset), _p(self.g_coset_inv)),
+               "h2hip_coeff_to_extended_bn254_fr")
+        return out
+
+    def extended_to_coeff(self, a):
+        """poly/domain.rs:281-303 (including the truncate at :299-300)"""
+        a = _u64(a, 4).copy()
+        assert a.shape[0] == self.extended_len()
+        _check(lib().h2hip_extended_to_coeff_bn254_fr(_p(a), ctypes.c_uint32(self.extended_k), _p(self.extended_omega_inv),
+                                                      _p(self.extended_ifft_divisor), _p(self.g_coset), _p(self.g_coset_inv)),
+               "h2hip_extended_to_coeff_bn254_fr")
+        return a[: self.n * self.quotient_poly_degree]
+
+
+# ------------------------------------------------------------------ poly/kzg/commitment.rs
+class ParamsKZG:
+    """poly::kzg::commitment::ParamsKZG<Bn256> (poly/kzg/commitment.rs:22-30): g and g_lagrange
+    are pinned on the GPU for the life of the object; commit / commit_lagrange are
+    best_multiexp over them (:281-292, :327-334; the blind is ignored there too)."""
+
+    def __init__(self, k, g, g_lagrange):
+        self.k, self.n = int(k), 1 << int(k)
+        self.g = _u64(g, 8).copy()
+        self.g_lagrange = _u64(g_lagrange, 8).copy()
+        assert self.g.shape[0] == self.n and self.g_lagrange.shape[0] == self.n
+        bases_pin(self.g)
+        bases_pin(self.g_lagrange)
+
+    def commit_lagrange(self, poly, blind=None):
+        poly = _u64(poly, 4)
+        size = poly.shape[0]
+        assert self.g_lagrange.shape[0] >= size  # assert!(bases.len() >= size), :290
+        out = np.zeros(12, dtype=np.uint64)
+        _check(lib().h2hip_msm_bn254(_p(poly), _p(self.g_lagrange), ctypes.c_size_t(size), _p(out)), "h2hip_msm_bn254")
+        return out
+
+    def commit(self, poly, blind=None):
+        poly = _u64(poly, 4)
+        size = poly.shape[0]
+        assert self.g.shape[0] >= size  # :332
+        out = np.zeros(12, dtype=np.uint64)
+        _check(lib().h2hip_msm_bn254(_p(poly), _p(self.g), ctypes.c_size_t(size), _p(out)), "h2hip_msm_bn254")
+        return out
+
+    def close(self):
+        for b in (self.g, self.g_lagrange):
+            try:
+                bases_unpin(b)
+            except H2HipError:
+                pass
+
+
+# ------------------------------------------------------------------ device-resident entry points
+def _dptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def msm_device(d_scalars, d_bases, n=None):
+    """d_scalars / d_bases: torch CUDA tensors holding n x 32 B and n x 64 B (any dtype)"""
+    nb = d_scalars.numel() * d_scalars.element_size()
+    n = nb // 32 if n is None else int(n)
+    out = np.zeros(12, dtype=np.uint64)
+    _check(lib().h2hip_msm_bn254_device(_dptr(d_scalars), _dptr(d_bases), ctypes.c_size_t(n), _p(out), _stream()), "h2hip_msm_bn254_device")
+    return out
+
+
+def ntt_device(d_a, omega, log_n):
+    _check(lib().h2hip_ntt_bn254_fr_device(_dptr(d_a), _p(_fe(omega)), ctypes.c_uint32(log_n), _stream()), "h2hip_ntt_bn254_fr_device")
+
+
+def ifft_device(d_a, omega_inv, log_n, divisor):
+    _check(lib().h2hip_ifft_bn254_fr_device(_dptr(d_a), _p(_fe(omega_inv)), ctypes.c_uint32(log_n), _p(_fe(divisor)), _stream()),
+           "h2hip_ifft_bn254_fr_device")
+
+
+def coeff_to_extended_device(d_a, k, extended_k, extended_omega, g_coset, g_coset_inv):
+    _check(lib().h2hip_coeff_to_extended_bn254_fr_device(_dptr(d_a), ctypes.c_uint32(k), ctypes.c_uint32(extended_k), _p(_fe(extended_omega)),
+                                                         _p(_fe(g_coset)), _p(_fe(g_coset_inv)), _stream()),
+           "h2hip_coeff_to_extended_bn254_fr_device")
+
+
+def extended_to_coeff_device(d_a, extended_k, extended_omega_inv, extended_ifft_divisor, g_coset, g_coset_inv):
+    _check(lib().h2hip_extended_to_coeff_bn254_fr_device(_dptr(d_a), ctypes.c_uint32(extended_k), _p(_fe(extended_omega_inv)),
+                                                         _p(_fe(extended_ifft_divisor)), _p(_fe(g_coset)), _p(_fe(g_coset_inv)), _stream()),
+           "h2hip_extended_to_coeff_bn254_fr_device")
+
+
+def gen_scalars_device(seed, n, start=0, device="cuda"):
+    import torch
+    out = torch.empty((n, 4), dtype=torch.int64, device=device)
+    _check(lib().h2hip_gen_scalars_device(ctypes.c_uint64(seed), ctypes.c_uint64(start), ctypes.c_size_t(n), _dptr(out), _stream()),
+           "h2hip_gen_scalars_device")
+    return out
+
+
+def gen_points_device(seed, n, start=0, device="cuda"):
+    import torch
+    out = torch.empty((n, 8), dtype=torch.int64, device=device)
+    _check(lib().h2hip_gen_points_device(ctypes.c_uint64(seed), ctypes.c_uint64(start), ctypes.c_size_t(n), _dptr(out), _stream()),
+           "h2hip_gen_points_device")
+    return out
+
+
+def to_numpy_u64(t):
+    return t.detach().cpu().numpy().view(np.uint64)
+
+
+# ------------------------------------------------------------------ tuning / measurement
+def set_msm_window(c):
+    _check(lib().h2hip_set_msm_window(ctypes.c_uint32(c)), "h2hip_set_msm_window")
+
+
+def get_msm_window(n):
+    return int(lib().h2hip_get_msm_window(n))
+
+
+def profile_enable(on=True):
+    _check(lib().h2hip_profile_enable(1 if on else 0), "h2hip_profile_enable")
+
+
+def profile_reset():
+    _check(lib().h2hip_profile_reset(), "h2hip_profile_reset")
+
+
+def profile_get(stage):
+    ms = ctypes.c_double(0)
+    cnt = ctypes.c_uint64(0)
+    _check(lib().h2hip_profile_get(stage.encode(), ctypes.byref(ms), ctypes.byref(cnt)), "h2hip_profile_get")
+    return ms.value, cnt.value

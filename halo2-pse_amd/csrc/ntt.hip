@@ -1,0 +1,284 @@
+// ntt.hip -- radix-2^s multi-pass NTT over BN254 Fr for gfx950.
+//
+// Computes exactly what halo2_proofs::arithmetic::best_fft computes for G = Fr
+// (halo2_proofs/src/arithmetic.rs:171-234): a[i] <- sum_j a[j] * omega^(i*j), natural order in
+// and out, in place, for omega of exact order 2^log_n.  Field arithmetic is exact, so any
+// butterfly schedule gives the reference's limbs bit for bit.
+//
+// Schedule (decimation in frequency, one HBM round trip per pass): pass t takes blocks of length
+// M, views each as R x (M/R) (R = 2^s rows at stride M/R), loads J adjacent columns into LDS,
+// runs the R-point DFT per column in LDS with the w_R table staged in LDS, multiplies output row
+// k of column lo by w_M^(k*lo) and stores it back to row k.  After the strided passes the
+// result is in digit-reversed order by blocks; the last pass (M = R, contiguous blocks) undoes
+// that on its store, writing J consecutive outputs per row so stores stay coalesced.  The
+// pointwise steps that surround best_fft in poly/domain.rs (zeta coset scaling + zero padding
+// on the way in, :246-247; 1/n and zeta^-1 scaling on the way out, :294, :355-360) are fused
+// into the first load and the last store.
+#include <string.h>
+
+#include "engine.h"
+
+namespace h2 {
+
+struct NttPass {
+    const Fe* src;
+    Fe* dst;
+    const Fe* tw_lo;
+    const Fe* tw_hi;
+    uint64_t in_len;
+    uint32_t log_n, log_m, s, log_j, lo_bits;
+    uint32_t first, in_scale, out_scale;
+    uint32_t n_prev;
+    uint32_t prev_s[4];
+    Fe in3[3], out3[3];
+};
+
+#define NTT_THREADS 256
+
+__device__ __forceinline__ Fe tw_pow(const NttPass& p, uint64_t e) {
+    uint32_t lo = (uint32_t)(e & ((1ull << p.lo_bits) - 1));
+    uint64_t hi = e >> p.lo_bits;
+    Fe a = p.tw_lo[lo];
+    if (hi) a = fe_mul<FrP>(a, p.tw_hi[hi]);
+    return a;
+}
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t k, uint32_t s) { return __brev(k) >> (32 - s); }
+
+// R-point DFT (DIF, output bit-reversed inside the column) on J columns held in LDS as x[col*R + r]
+__device__ __forceinline__ void dft_lds(Fe* x, const Fe* wtab, uint32_t s, uint32_t log_j) {
+    const uint32_t R = 1u << s;
+    const uint32_t nbf = (R << log_j) >> 1;
+    uint32_t log_h = s - 1;
+    for (uint32_t h = R >> 1; h >= 1; h >>= 1, log_h--) {
+        for (uint32_t bf = threadIdx.x; bf < nbf; bf += NTT_THREADS) {
+            uint32_t col = bf >> (s - 1);
+            uint32_t i = bf & ((R >> 1) - 1);
+            uint32_t off = i & (h - 1);
+            uint32_t blk = i >> log_h;
+            uint32_t i0 = (col << s) + (blk << (log_h + 1)) + off;
+            uint32_t i1 = i0 + h;
+            Fe a = x[i0], b = x[i1];
+            x[i0] = fe_add<FrP>(a, b);
+            Fe d = fe_sub<FrP>(a, b);
+            if (off) d = fe_mul<FrP>(d, wtab[off << (s - 1 - log_h)]);
+            x[i1] = d;
+        }
+        __syncthreads();
+        if (h == 1) break;
+    }
+}
+
+__device__ __forceinline__ Fe ntt_load(const NttPass& p, uint64_t gi) {
+    if (p.first) {
+        if (gi >= p.in_len) return fe_zero<FrP>();
+        Fe v = p.src[gi];
+        if (p.in_scale) {
+            uint32_t m = (uint32_t)(gi % 3);
+            if (m) v = fe_mul<FrP>(v, p.in3[m]);
+        }
+        return v;
+    }
+    return p.src[gi];
+}
+
+extern __shared__ __align__(16) unsigned char ntt_lds_raw[];
+
+__global__ void __launch_bounds__(NTT_THREADS) ntt_strided_kernel(NttPass p) {
+    Fe* x = reinterpret_cast<Fe*>(ntt_lds_raw);
+    const uint32_t R = 1u << p.s, J = 1u << p.log_j;
+    Fe* wtab = x + (R << p.log_j);
+    const uint32_t log_l = p.log_m - p.s;                 // L = M/R columns per block
+    const uint32_t log_gpb = log_l - p.log_j;             // column groups per block
+    const uint64_t u = blockIdx.x;
+    const uint64_t base = (u >> log_gpb) << p.log_m;
+    const uint64_t lo0 = (u & ((1ull << log_gpb) - 1)) << p.log_j;
+    for (uint32_t i = threadIdx.x; i < (R >> 1); i += NTT_THREADS) wtab[i] = tw_pow(p, (uint64_t)i << (p.log_n - p.s));
+    for (uint32_t idx = threadIdx.x; idx < (R << p.log_j); idx += NTT_THREADS) {
+        uint32_t r = idx >> p.log_j, jj = idx & (J - 1);
+        x[(jj << p.s) + r] = ntt_load(p, base + ((uint64_t)r << log_l) + lo0 + jj);
+    }
+    __syncthreads();
+    dft_lds(x, wtab, p.s, p.log_j);
+    for (uint32_t idx = threadIdx.x; idx < (R << p.log_j); idx += NTT_THREADS) {
+        uint32_t k = idx >> p.log_j, jj = idx & (J - 1);
+        Fe v = x[(jj << p.s) + bitrev(k, p.s)];
+        uint64_t lo = lo0 + jj;
+        uint64_t e = ((uint64_t)k * lo) << (p.log_n - p.log_m);  // w_M^(k*lo) = omega^((N/M)*k*lo)
+        if (e) v = fe_mul<FrP>(v, tw_pow(p, e));
+        p.dst[base + ((uint64_t)k << log_l) + lo] = v;
+    }
+}
+
+__global__ void __launch_bounds__(NTT_THREADS) ntt_final_kernel(NttPass p) {
+    Fe* x = reinterpret_cast<Fe*>(ntt_lds_raw);
+    const uint32_t R = 1u << p.s, J = 1u << p.log_j;
+    Fe* wtab = x + (R << p.log_j);
+    const uint64_t g = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < (R >> 1); i += NTT_THREADS) wtab[i] = tw_pow(p, (uint64_t)i << (p.log_n - p.s));
+    for (uint32_t idx = threadIdx.x; idx < (R << p.log_j); idx += NTT_THREADS) {
+        uint32_t jj = idx >> p.s, r = idx & (R - 1);
+        // block whose digit-reversed index is g*J + jj
+        uint64_t v = (g << p.log_j) + jj, bi = 0;
+        for (uint32_t t = 0; t < p.n_prev; t++) {
+            bi = (bi << p.prev_s[t]) | (v & ((1ull << p.prev_s[t]) - 1));
+            v >>= p.prev_s[t];
+        }
+        x[(jj << p.s) + r] = ntt_load(p, (bi << p.s) + r);
+    }
+    __syncthreads();
+    dft_lds(x, wtab, p.s, p.log_j);
+    const uint32_t log_nb = p.log_n - p.s;
+    for (uint32_t idx = threadIdx.x; idx < (R << p.log_j); idx += NTT_THREADS) {
+        uint32_t k = idx >> p.log_j, jj = idx & (J - 1);
+        Fe v = x[(jj << p.s) + bitrev(k, p.s)];
+        uint64_t oi = ((uint64_t)k << log_nb) + (g << p.log_j) + jj;
+        if (p.out_scale) v = fe_mul<FrP>(v, p.out3[oi % 3]);
+        p.dst[oi] = v;
+    }
+}
+
+// n = 1: best_fft is the identity; only the fused scales apply
+__global__ void ntt_n1_kernel(NttPass p) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        Fe v = ntt_load(p, 0);
+        if (p.out_scale) v = fe_mul<FrP>(v, p.out3[0]);
+        p.dst[0] = v;
+    }
+}
+
+__global__ void twiddle_build_kernel(Fe omega, Fe* lo, uint32_t n_lo, Fe* hi, uint32_t n_hi, uint32_t lo_bits) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_lo) {
+        lo[i] = fe_pow_u64<FrP>(omega, i);
+    } else if (i < n_lo + n_hi) {
+        uint32_t j = i - n_lo;
+        hi[j] = fe_pow_u64<FrP>(omega, (uint64_t)j << lo_bits);
+    }
+}
+
+static int get_twiddles(Ctx* c, const Fe& omega, uint32_t log_n, hipStream_t s, TwiddleTable* out) {
+    TwiddleKey key;
+    for (int i = 0; i < 8; i++) key.omega[i] = omega.l[i];
+    key.log_n = log_n;
+    auto it = c->twiddles.find(key);
+    if (it != c->twiddles.end()) {
+        *out = it->second;
+        return 0;
+    }
+    TwiddleTable t;
+    t.lo_bits = log_n < 10 ? log_n : 10;
+    uint32_t n_lo = 1u << t.lo_bits, n_hi = 1u << (log_n - t.lo_bits);
+    H2_CHECK(hipMalloc((void**)&t.lo, (size_t)n_lo * sizeof(Fe)));
+    H2_CHECK(hipMalloc((void**)&t.hi, (size_t)n_hi * sizeof(Fe)));
+    uint32_t total = n_lo + n_hi;
+    hipLaunchKernelGGL(twiddle_build_kernel, dim3((total + 255) / 256), dim3(256), 0, s, omega, t.lo, n_lo, t.hi, n_hi, t.lo_bits);
+    H2_CHECK(hipGetLastError());
+    H2_CHECK(hipStreamSynchronize(s));  // built once per (omega, log_n); later calls may use another stream
+    if (c->twiddles.size() >= 64) {  // bounded cache: a prover uses a handful of domains
+        H2_CHECK(hipDeviceSynchronize());
+        for (auto& kv : c->twiddles) {
+            (void)hipFree(kv.second.lo);
+            (void)hipFree(kv.second.hi);
+        }
+        c->twiddles.clear();
+    }
+    c->twiddles[key] = t;
+    *out = t;
+    return 0;
+}
+
+// pass radices: one pass up to 2^10, otherwise ceil(log_n / 8) passes of near-equal radix
+static int plan_passes(uint32_t log_n, uint32_t s_out[4]) {
+    if (log_n <= 10) {
+        s_out[0] = log_n;
+        return 1;
+    }
+    int P = (int)((log_n + 7) / 8);
+    uint32_t base = log_n / P, rem = log_n % P;
+    for (int t = 0; t < P; t++) s_out[t] = base + ((uint32_t)t < rem ? 1 : 0);
+    return P;
+}
+
+int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttScale* sc, hipStream_t s) {
+    if (log_n > FrP::S) {
+        set_error("ntt: log_n=%u exceeds the 2-adicity of Fr (28)", log_n);
+        return 1;
+    }
+    NttPass p;
+    memset(&p, 0, sizeof(p));
+    p.log_n = log_n;
+    p.in_len = 1ull << log_n;
+    if (sc) {
+        p.in_scale = sc->in_scale;
+        p.out_scale = sc->out_scale;
+        if (sc->in_len) p.in_len = sc->in_len;
+        for (int i = 0; i < 3; i++) {
+            p.in3[i] = sc->in3[i];
+            p.out3[i] = sc->out3[i];
+        }
+    }
+    int rc0 = c->ws_acquire(s);
+    if (rc0) return rc0;
+    int tid = c->timer_begin("ntt", s);
+    if (log_n == 0) {
+        p.src = d_data;
+        p.dst = d_data;
+        p.first = 1;
+        hipLaunchKernelGGL(ntt_n1_kernel, dim3(1), dim3(64), 0, s, p);
+        H2_CHECK(hipGetLastError());
+        c->timer_end(tid, s);
+        return c->ws_release(s);
+    }
+    TwiddleTable tw;
+    int rc = get_twiddles(c, omega, log_n, s, &tw);
+    if (rc) return rc;
+    p.tw_lo = tw.lo;
+    p.tw_hi = tw.hi;
+    p.lo_bits = tw.lo_bits;
+    uint32_t S[4];
+    int P = plan_passes(log_n, S);
+    Fe* ws = nullptr;
+    if (P > 1) {
+        rc = c->ntt_ws.ensure(sizeof(Fe) << log_n);
+        if (rc) return rc;
+        ws = (Fe*)c->ntt_ws.p;
+    }
+    uint32_t log_m = log_n;
+    for (int t = 0; t < P; t++) {
+        p.s = S[t];
+        p.log_m = log_m;
+        p.first = (t == 0);
+        bool final = (t == P - 1);
+        if (final) {
+            p.src = (P == 1) ? d_data : ws;
+            p.dst = d_data;
+            uint32_t log_nb = log_n - p.s;
+            p.log_j = log_nb < 2 ? log_nb : 2;
+            p.n_prev = (uint32_t)(P - 1);
+            for (int q = 0; q < P - 1; q++) p.prev_s[q] = S[q];
+        } else {
+            bool to_ws = (t == P - 2);  // last strided pass goes out of place so the final pass lands in d_data
+            p.src = d_data;
+            p.dst = to_ws ? ws : d_data;
+            uint32_t log_l = log_m - p.s;
+            p.log_j = log_l < 2 ? log_l : 2;
+        }
+        size_t lds = (((size_t)1 << (p.s + p.log_j)) + ((size_t)1 << p.s) / 2 + 1) * sizeof(Fe);
+        uint64_t grid = 1ull << (log_n - p.s - p.log_j);
+        if (grid > 0x7fffffffull) {
+            set_error("ntt: grid too large");
+            return 1;
+        }
+        if (final)
+            hipLaunchKernelGGL(ntt_final_kernel, dim3((uint32_t)grid), dim3(NTT_THREADS), lds, s, p);
+        else
+            hipLaunchKernelGGL(ntt_strided_kernel, dim3((uint32_t)grid), dim3(NTT_THREADS), lds, s, p);
+        H2_CHECK(hipGetLastError());
+        log_m -= p.s;
+    }
+    c->timer_end(tid, s);
+    return c->ws_release(s);
+}
+
+}  // namespace h2

@@ -1,0 +1,134 @@
+/*
+ * halo2hip.h -- C ABI of libhalo2hip.so, the MI355X (gfx950) engine for the halo2_proofs
+ * proving hot path: BN254 G1 multi-scalar multiplication and the radix-2 NTT over BN254 Fr.
+ *
+ * The reference (eldenpark/halo2-pse, Rust) has no FFI layer: the seam is two generic free
+ * functions plus the KZG commit methods built on them.  Each entry point below names the
+ * reference interface it replaces (paths relative to halo2_proofs/src/ in the reference);
+ * INTEGRATION.md shows the Rust `extern "C"` block and the two-line dispatch patch.
+ *
+ * Data layout at the boundary (identical to halo2curves 0.3.1 in memory and to
+ * SerdeFormat::RawBytes, helpers.rs:13-19):
+ *   Fr / Fq element : 4 x uint64_t little-endian limbs, Montgomery form (R = 2^256), < modulus
+ *   G1Affine        : x || y            (8 x uint64_t, 64 B), identity = all zero
+ *   G1 (projective) : x || y || z       (12 x uint64_t, 96 B), Jacobian, identity z = 0
+ *
+ * Conventions: every function returns 0 on success and a non-zero H2HIP_E* code otherwise
+ * (never throws / unwinds; the Rust shim falls back to the original CPU body on non-zero).
+ * h2hip_last_error() describes the last failure on the calling thread.  All entry points are
+ * thread-safe and blocking; one process drives one GPU (the current HIP device at init).
+ * There is no CPU fallback inside the library: without a usable GPU every compute entry
+ * point fails with H2HIP_EDEVICE.
+ */
+#ifndef HALO2HIP_H
+#define HALO2HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define H2HIP_OK 0
+#define H2HIP_EINVAL 1   /* contract violation (the reference would panic: arithmetic.rs:133,184) */
+#define H2HIP_EDEVICE 2  /* HIP runtime / device error, or no GPU */
+#define H2HIP_ENOMEM 3
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+
+/* Bind the engine to a GPU.  device_ids == NULL or n_devices == 0: use the calling thread's
+ * current HIP device.  Idempotent.  (Multi-GPU MSM runs one process per GPU, see
+ * h2hip_g1_fold.) */
+int h2hip_init(const int* device_ids, int n_devices);
+void h2hip_shutdown(void);
+const char* h2hip_last_error(void);
+const char* h2hip_version(void);
+/* number of visible HIP devices, or -1 when the runtime reports an error */
+int h2hip_device_count(void);
+
+/* ---- best_multiexp: arithmetic.rs:132-159 ------------------------------------------------ */
+
+/* out = sum_i scalars[i] * bases[i].  Replaces
+ *   pub fn best_multiexp<C: CurveAffine>(coeffs: &[C::Scalar], bases: &[C]) -> C::Curve
+ * for C = bn256::G1Affine, and through it ParamsKZG::commit / commit_lagrange
+ * (poly/kzg/commitment.rs:281-292, :327-334) and MSMKZG::eval (poly/kzg/msm.rs:65-70).
+ * Host pointers; n == 0 gives the identity.  The group element equals the reference's for
+ * every thread count; Jacobian coordinates are not specified by the reference
+ * (they depend on rayon's thread count, arithmetic.rs:153). */
+int h2hip_msm_bn254(const uint64_t* scalars, const uint64_t* bases_xy, size_t n, uint64_t out_xyz[12]);
+
+/* Keep a copy of `bases_xy[0..n)` on the GPU, keyed by the host pointer: later
+ * h2hip_msm_bn254 calls whose bases pointer equals `bases_xy` (and n' <= n) skip the upload.
+ * For ParamsKZG::{g, g_lagrange} (poly/kzg/commitment.rs:26-27), which live as long as the
+ * params; call unpin before the Vec is dropped or mutated (downsize, :267-275). */
+int h2hip_bases_pin(const uint64_t* bases_xy, size_t n);
+int h2hip_bases_unpin(const uint64_t* bases_xy);
+
+/* Same computation on device-resident inputs (scalars n x 32 B, bases n x 64 B in HBM);
+ * `stream` is a hipStream_t; NULL is HIP's default (null) stream, as everywhere in HIP.  All
+ * kernels are enqueued on that stream, so the inputs may be produced by earlier work on it;
+ * the call returns after the stream is synchronised and the result is in host memory. */
+int h2hip_msm_bn254_device(const void* d_scalars, const void* d_bases_xy, size_t n, uint64_t out_xyz[12], void* stream);
+
+/* Left fold of k Jacobian partial sums from the identity -- the fold at arithmetic.rs:153.
+ * Multi-GPU MSM: each rank computes its shard's partial with h2hip_msm_bn254[_device], the
+ * 96-byte partials are all-gathered (RCCL, bytes), and every rank folds them with this. */
+int h2hip_g1_fold(const uint64_t* partials_xyz, size_t k, uint64_t out_xyz[12]);
+/* Curve::to_affine; identity -> (0,0) */
+int h2hip_g1_to_affine(const uint64_t xyz[12], uint64_t xy[8]);
+
+/* ---- best_fft and the EvaluationDomain conversions built on it --------------------------- */
+
+/* In-place radix-2 NTT, natural order in and out: a[i] <- sum_j a[j] * omega^(i*j).  Replaces
+ *   pub fn best_fft<G: Group>(a: &mut [G], omega: G::Scalar, log_n: u32)       arithmetic.rs:171
+ * for G = bn256::Fr.  `a` has 2^log_n elements; omega must have exact order 2^log_n (true for
+ * every in-crate caller: poly/domain.rs:248,354); log_n <= 28. */
+int h2hip_ntt_bn254_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n);
+int h2hip_ntt_bn254_fr_device(void* d_a, const uint64_t omega[4], uint32_t log_n, void* stream);
+
+/* EvaluationDomain::ifft (poly/domain.rs:353-361): best_fft(a, omega_inv, log_n) then
+ * a[i] *= divisor, fused into one device round trip.  lagrange_to_coeff (:226-236) is this
+ * with (omega_inv, k, ifft_divisor). */
+int h2hip_ifft_bn254_fr(uint64_t* a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4]);
+int h2hip_ifft_bn254_fr_device(void* d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], void* stream);
+
+/* EvaluationDomain::coeff_to_extended (poly/domain.rs:240-254): out[0..2^extended_k) =
+ * best_fft(zero-pad(distribute_powers_zeta(a[0..2^k), into_coset = true)), extended_omega).
+ * g_coset = ZETA, g_coset_inv = ZETA^2 as stored in the domain (:81-82). */
+int h2hip_coeff_to_extended_bn254_fr(const uint64_t* a, uint32_t k, uint64_t* out, uint32_t extended_k,
+                                     const uint64_t extended_omega[4], const uint64_t g_coset[4], const uint64_t g_coset_inv[4]);
+/* device form: d_a holds 2^extended_k elements of which the first 2^k are the input */
+int h2hip_coeff_to_extended_bn254_fr_device(void* d_a, uint32_t k, uint32_t extended_k, const uint64_t extended_omega[4],
+                                            const uint64_t g_coset[4], const uint64_t g_coset_inv[4], void* stream);
+
+/* EvaluationDomain::extended_to_coeff (poly/domain.rs:281-303) without the final truncate:
+ * ifft(a, extended_omega_inv, extended_k, extended_ifft_divisor) then
+ * distribute_powers_zeta(a, into_coset = false), in place on 2^extended_k elements. */
+int h2hip_extended_to_coeff_bn254_fr(uint64_t* a, uint32_t extended_k, const uint64_t extended_omega_inv[4],
+                                     const uint64_t extended_ifft_divisor[4], const uint64_t g_coset[4], const uint64_t g_coset_inv[4]);
+int h2hip_extended_to_coeff_bn254_fr_device(void* d_a, uint32_t extended_k, const uint64_t extended_omega_inv[4],
+                                            const uint64_t extended_ifft_divisor[4], const uint64_t g_coset[4],
+                                            const uint64_t g_coset_inv[4], void* stream);
+
+/* ---- synthetic workload; same streams as oracle_gen_{scalars,points} ---- */
+
+int h2hip_gen_scalars_device(uint64_t seed, uint64_t start, size_t n, void* d_out, void* stream);
+int h2hip_gen_points_device(uint64_t seed, uint64_t start, size_t n, void* d_out, void* stream);
+
+/* ---- tuning and measurement ----------------------------------------------------------------- */
+
+/* MSM window width in bits (2..22); 0 restores the size-based default */
+int h2hip_set_msm_window(uint32_t c);
+/* window width the engine would use for n pairs */
+uint32_t h2hip_get_msm_window(size_t n);
+/* Per-stage HIP-event timers recorded on the stream each kernel group is launched on.
+ * Stages: "ntt", "msm_total", "msm_digits", "msm_sort", "msm_accum", "msm_heavy", "msm_reduce". */
+int h2hip_profile_enable(int on);
+int h2hip_profile_reset(void);
+int h2hip_profile_get(const char* stage, double* total_ms, uint64_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HALO2HIP_H */

@@ -1,0 +1,236 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the
+golden vectors.  Bit-exact: NTT outputs limb for limb, MSM outputs after normalising to affine
+(SURVEY.md Appendix B).  Run with `pytest -m gpu` on an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MSM_CASES = ["1", "2", "3", "4", "31", "32", "33", "100", "1024", "zeros", "ones", "rm1", "single", "sparse", "cancel"]
+NT = min(16, os.cpu_count() or 1)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _engine(h2):
+    h2.init()
+    yield
+    h2.set_msm_window(0)
+
+
+def aff(h2, xyz):
+    return h2.g1_to_affine(xyz)
+
+
+# ---------------------------------------------------------------------------- MSM
+@pytest.mark.parametrize("case", MSM_CASES)
+def test_msm_golden(h2, golden, case):
+    got = aff(h2, h2.best_multiexp(golden[f"msm_{case}_scalars"], golden[f"msm_{case}_bases"]))
+    assert np.array_equal(got, golden[f"msm_{case}_result"])
+
+
+@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 13, 16])
+def test_msm_golden_all_window_widths(h2, golden, c):
+    h2.set_msm_window(c)
+    try:
+        for case in ("33", "1024", "sparse", "rm1"):
+            got = aff(h2, h2.best_multiexp(golden[f"msm_{case}_scalars"], golden[f"msm_{case}_bases"]))
+            assert np.array_equal(got, golden[f"msm_{case}_result"]), (c, case)
+    finally:
+        h2.set_msm_window(0)
+
+
+def test_msm_empty(h2):
+    out = h2.best_multiexp(np.zeros((0, 4), dtype=np.uint64), np.zeros((0, 8), dtype=np.uint64))
+    assert np.array_equal(aff(h2, out), np.zeros(8, dtype=np.uint64))
+
+
+@pytest.mark.parametrize("n", [1 << 10, (1 << 12) + 37, 1 << 14, 1 << 16])
+def test_msm_vs_oracle_seeded(h2, oracle, n):
+    sc = oracle.gen_scalars(0x5EED0001, n, num_threads=NT)
+    bs = oracle.gen_points(0x5EED0002, n, num_threads=NT)
+    want = oracle.g1_to_affine(oracle.best_multiexp(sc, bs, NT))
+    got = aff(h2, h2.best_multiexp(sc, bs))
+    assert np.array_equal(got, want)
+
+
+def _prover_like(oracle, n, seed):
+    # 90 % zero, 5 % in {1,2}, 5 % uniform
+    rng = np.random.default_rng(seed)
+    sc = oracle.gen_scalars(seed, n, num_threads=NT)
+    u = rng.random(n)
+    one = oracle.fe_from_int(oracle.FR, 1)
+    two = oracle.fe_from_int(oracle.FR, 2)
+    sc[u < 0.90] = 0
+    sc[(u >= 0.90) & (u < 0.925)] = one
+    sc[(u >= 0.925) & (u < 0.95)] = two
+    return sc
+
+
+def test_msm_skewed_scalars_heavy_buckets(h2, oracle):
+    n = 1 << 14
+    bs = oracle.gen_points(77, n, num_threads=NT)
+    # every scalar equal: one over-full bucket per window (chunked path, several chunks)
+    sc = np.repeat(oracle.gen_scalars(78, 1), n, axis=0)
+    want = oracle.g1_to_affine(oracle.best_multiexp(sc, bs, NT))
+    assert np.array_equal(aff(h2, h2.best_multiexp(sc, bs)), want)
+    # prover-like sparse column
+    sc = _prover_like(oracle, n, 79)
+    want = oracle.g1_to_affine(oracle.best_multiexp(sc, bs, NT))
+    assert np.array_equal(aff(h2, h2.best_multiexp(sc, bs)), want)
+    # all bases equal and all scalars equal: doubling inside buckets and inside the tree
+    bs1 = np.repeat(bs[:1], n, axis=0)
+    want = oracle.g1_to_affine(oracle.best_multiexp(sc, bs1, NT))
+    assert np.array_equal(aff(h2, h2.best_multiexp(sc, bs1)), want)
+
+
+def test_msm_pinned_bases_and_prefix(h2, oracle):
+    n = 1 << 12
+    sc = oracle.gen_scalars(5, n, num_threads=NT)
+    bs = oracle.gen_points(6, n, num_threads=NT)
+    h2.bases_pin(bs)
+    try:
+        for m in (n, n // 2, 100):
+            want = oracle.g1_to_affine(oracle.best_multiexp(sc[:m], bs[:m], NT))
+            got = h2.best_multiexp(sc[:m], bs[:m])  # a view that starts at the pinned pointer: no re-upload
+            assert np.array_equal(aff(h2, got), want)
+    finally:
+        h2.bases_unpin(bs)
+    with pytest.raises(h2.H2HipError):
+        h2.bases_unpin(bs)
+
+
+def test_generators_match_oracle(h2, oracle, golden):
+    ds = h2.gen_scalars_device(0x5EED0001, 4096)
+    dp = h2.gen_points_device(0x5EED0002, 4096)
+    s, p = h2.to_numpy_u64(ds), h2.to_numpy_u64(dp)
+    assert np.array_equal(s[:64], golden["gen_scalars_5EED0001"])
+    assert np.array_equal(p[:64], golden["gen_points_5EED0002"])
+    assert np.array_equal(s, oracle.gen_scalars(0x5EED0001, 4096, num_threads=NT))
+    assert np.array_equal(p, oracle.gen_points(0x5EED0002, 4096, num_threads=NT))
+    ds = h2.gen_scalars_device(0x5EED0001, 8, start=1000)
+    assert np.array_equal(h2.to_numpy_u64(ds), golden["gen_scalars_offset1000"])
+    dp = h2.gen_points_device(0x5EED0002, 8, start=1000)
+    assert np.array_equal(h2.to_numpy_u64(dp), golden["gen_points_offset1000"])
+
+
+def test_msm_device_entry_point(h2, oracle):
+    n = 1 << 13
+    ds = h2.gen_scalars_device(0x5EED0001, n)
+    dp = h2.gen_points_device(0x5EED0002, n)
+    got = aff(h2, h2.msm_device(ds, dp))
+    want = oracle.g1_to_affine(oracle.best_multiexp(h2.to_numpy_u64(ds), h2.to_numpy_u64(dp), NT))
+    assert np.array_equal(got, want)
+
+
+def test_msm_full_size_2p20(h2, oracle):
+    """BASELINE.json configs[1]: 2^20 pairs on one MI355X, bit-exact vs the CPU path; plus the
+    size-independent shard/fold property used by the multi-GPU path."""
+    n = 1 << 20
+    ds = h2.gen_scalars_device(0x5EED0001, n)
+    dp = h2.gen_points_device(0x5EED0002, n)
+    full = h2.msm_device(ds, dp)
+    sc, bs = h2.to_numpy_u64(ds), h2.to_numpy_u64(dp)
+    want = oracle.g1_to_affine(oracle.best_multiexp(sc, bs, NT))
+    assert np.array_equal(aff(h2, full), want)
+    parts = [h2.msm_device(ds[i * (n // 4):(i + 1) * (n // 4)], dp[i * (n // 4):(i + 1) * (n // 4)]) for i in range(4)]
+    assert np.array_equal(aff(h2, h2.g1_fold(np.stack(parts))), want)
+
+
+# ---------------------------------------------------------------------------- NTT
+@pytest.mark.parametrize("k", range(0, 11))
+def test_ntt_golden(h2, golden, k):
+    a = golden[f"ntt_{k}_in"].copy()
+    h2.best_fft(a, golden[f"ntt_{k}_omega"], k)
+    assert np.array_equal(a, golden[f"ntt_{k}_out"])
+
+
+@pytest.mark.parametrize("k", [11, 12, 13, 15, 16, 17, 18, 20])
+def test_ntt_vs_oracle(h2, oracle, k):
+    d, _ = oracle.domain_new(2, k)
+    a = oracle.gen_scalars(0x5EED0003, 1 << k, num_threads=NT)
+    want = oracle.best_fft(a, d.fe("omega"), k, NT)
+    got = a.copy()
+    h2.best_fft(got, d.fe("omega"), k)
+    assert np.array_equal(got, want)
+    # and back: ifft returns the input (round trip) and equals the oracle's ifft
+    back = got.copy()
+    dom = _domain(h2, d)
+    back = dom.lagrange_to_coeff(back)
+    assert np.array_equal(back, a)
+
+
+def _domain(h2, d):
+    return h2.EvaluationDomain(d.k, d.extended_k, d.quotient_poly_degree, **{f: d.fe(f) for f in h2.EvaluationDomain.FIELDS})
+
+
+@pytest.mark.parametrize("jk", [(4, 5), (3, 4), (2, 3)])
+def test_domain_golden(h2, oracle, golden, jk):
+    j, k = jk
+    d, _ = oracle.domain_new(j, k)
+    dom = _domain(h2, d)
+    assert np.array_equal(dom.coeff_to_extended(golden[f"ext_{j}_{k}_coeffs"]), golden[f"ext_{j}_{k}_extended"])
+    assert np.array_equal(dom.extended_to_coeff(golden[f"ext_{j}_{k}_h_extended"]), golden[f"ext_{j}_{k}_h_coeffs"])
+
+
+@pytest.mark.parametrize("jk", [(4, 10), (4, 14), (3, 12), (2, 11), (4, 17)])
+def test_domain_vs_oracle(h2, oracle, jk):
+    j, k = jk
+    d, _ = oracle.domain_new(j, k)
+    dom = _domain(h2, d)
+    a = oracle.gen_scalars(1234 + k, 1 << k, num_threads=NT)
+    ext = dom.coeff_to_extended(a)
+    assert np.array_equal(ext, oracle.coeff_to_extended(d, a, NT))
+    h = oracle.gen_scalars(4321 + k, 1 << d.extended_k, num_threads=NT)
+    assert np.array_equal(dom.extended_to_coeff(h), oracle.extended_to_coeff(d, h, NT))
+    lag = oracle.gen_scalars(999 + k, 1 << k, num_threads=NT)
+    assert np.array_equal(dom.lagrange_to_coeff(lag), oracle.lagrange_to_coeff(d, lag, NT))
+
+
+def test_ntt_full_size_2p22_roundtrip_and_oracle(h2, oracle):
+    """BASELINE.json configs[2]: k = 22 NTT + iNTT on one MI355X (device-resident), each
+    direction equal to the oracle, and the round trip returns the input."""
+    import torch
+    k = 22
+    d, _ = oracle.domain_new(2, k)
+    da = h2.gen_scalars_device(0x5EED0003, 1 << k)
+    a = h2.to_numpy_u64(da).copy()
+    h2.ntt_device(da, d.fe("omega"), k)
+    torch.cuda.synchronize()
+    fwd = h2.to_numpy_u64(da).copy()
+    assert np.array_equal(fwd, oracle.best_fft(a, d.fe("omega"), k, NT))
+    h2.ifft_device(da, d.fe("omega_inv"), k, d.fe("ifft_divisor"))
+    torch.cuda.synchronize()
+    assert np.array_equal(h2.to_numpy_u64(da), a)
+
+
+@pytest.mark.parametrize("k", [6])
+def test_commit_lagrange_identity(h2, oracle, golden, k):
+    """poly/kzg/commitment.rs:361-384 test_commit_lagrange through the engine:
+    commit(lagrange_to_coeff(a)) == commit_lagrange(a), a[i] = i"""
+    params = h2.ParamsKZG(k, golden[f"kzg_{k}_g"], golden[f"kzg_{k}_g_lagrange"])
+    try:
+        d, _ = oracle.domain_new(1, k)
+        dom = _domain(h2, d)
+        a = golden[f"kzg_{k}_poly_lagrange"]
+        b = dom.lagrange_to_coeff(a)
+        assert np.array_equal(b, golden[f"kzg_{k}_poly_coeff"])
+        c1 = aff(h2, params.commit(b))
+        c2 = aff(h2, params.commit_lagrange(a))
+        assert np.array_equal(c1, c2)
+        assert np.array_equal(c1, golden[f"kzg_{k}_commit_lagrange"])
+    finally:
+        params.close()
+
+
+def test_contract_violations_are_errors_not_crashes(h2):
+    # the reference panics (assert_eq!, arithmetic.rs:133,184); the C ABI returns H2HIP_EINVAL
+    bad_omega = np.full(4, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+    a = np.zeros((4, 4), dtype=np.uint64)
+    with pytest.raises(h2.H2HipError):
+        h2.best_fft(a, bad_omega, 2)
+    with pytest.raises(AssertionError):
+        h2.best_fft(a, np.zeros(4, dtype=np.uint64), 3)
+    with pytest.raises(AssertionError):
+        h2.best_multiexp(np.zeros((2, 4), dtype=np.uint64), np.zeros((3, 8), dtype=np.uint64))
