@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- BN254 MSM (+ Fr NTT) throughput on MI355X, one process per GPU.
+
+Step = one pass of the hot path over one batch of synthetic input: one BN254 G1 MSM of
+2^LOG_N pairs per GPU (BASELINE.json configs[1]: 2^20 on one MI355X), inputs generated in HBM
+before the timed region (SplitMix64 scalars / try-and-increment points).
+With N > 1 ranks each rank runs the same-size shard (weak scaling), the 96-byte partials are
+all-gathered over RCCL and folded on every rank (arithmetic.rs:153).
+
+Prints ONE JSON line on rank 0.  `value` = bucket-accumulation G1 adds per second over the
+whole job = N * n * W / t (W = 254//c + 1 signed windows at the engine's window width c;
+SURVEY.md 8(d)); pairs/s and the NTT figure ride along as extra keys.  `roofline` prices the
+dominant kernel (msm_accum_kernel) at its algorithmic 96 B per pair against 8 TB/s, timed with
+HIP events on the stream it is launched on; `cpu_baseline` is the oracle's restatement of the
+reference's rayon path timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from __graft_entry__ import load_pkg  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+MSM_BYTES_PER_PAIR = 96  # 32 B scalar + 64 B affine point, read once
+NTT_BYTES_PER_ELEM = 64  # one 32 B read + one 32 B write per transform
+
+
+def pmc_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass
+    (profiles/*_pmc_traffic.json, made by tools/pmc_traffic.py), or None when absent."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d.get(workload, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=20, help="pairs per GPU = 2^log_n")
+    ap.add_argument("--ntt-log-n", type=int, default=22)
+    ap.add_argument("--window", type=int, default=0, help="MSM window bits (0 = engine default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ntt", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libhalo2hip has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    h2 = load_pkg()
+    from importlib import import_module
+    h2dist = import_module("halo2_pse_amd.dist")
+    h2.init(local_rank)
+    if args.window:
+        h2.set_msm_window(args.window)
+
+    n = 1 << args.log_n
+    c = h2.get_msm_window(n)
+    W = 254 // c + 1
+    # every rank draws its own shard of one global sequence (element index offset = rank * n)
+    d_scalars = h2.gen_scalars_device(0x5EED0001, n, start=rank * n, device=dev)
+    d_points = h2.gen_points_device(0x5EED0002, n, start=rank * n, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        part = h2.msm_device(d_scalars, d_points)
+        if world > 1:
+            return h2dist.allgather_fold(part, h2, device=dev)
+        return part
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        result = step()
+    h2.profile_enable(True)
+    h2.profile_reset()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    h2.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stages = {}
+    for st in ("msm_total", "msm_digits", "msm_sort", "msm_accum", "msm_heavy", "msm_reduce"):
+        ms, cnt = h2.profile_get(st)
+        stages[st] = ms / cnt if cnt else None
+
+    # ---- NTT leg (BASELINE.json configs[2]: k = 22 NTT + iNTT), outside the MSM timed region ----
+    ntt = None
+    if not args.no_ntt and rank == 0:
+        from oracle import oracle
+        k = args.ntt_log_n
+        d, _ = oracle.domain_new(2, k)
+        d_a = h2.gen_scalars_device(0x5EED0003, 1 << k, device=dev)
+        for _ in range(2):
+            h2.ntt_device(d_a, d.fe("omega"), k)
+            h2.ifft_device(d_a, d.fe("omega_inv"), k, d.fe("ifft_divisor"))
+        torch.cuda.synchronize()
+        reps = 10
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            h2.ntt_device(d_a, d.fe("omega"), k)
+            h2.ifft_device(d_a, d.fe("omega_inv"), k, d.fe("ifft_divisor"))
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / (2 * reps)
+        ntt = {
+            "log_n": k,
+            "ms_per_transform": ms,
+            "elems_per_s": (1 << k) / (ms * 1e-3),
+            "roofline": {"bound": "hbm", "achieved": NTT_BYTES_PER_ELEM * (1 << k) / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": NTT_BYTES_PER_ELEM * (1 << k) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+        }
+        del d_a
+
+    # ---- CPU baseline (rank 0, N = 1 only): the oracle's best_multiexp on the same inputs ----
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        cores = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU
+        sc, bs = h2.to_numpy_u64(d_scalars), h2.to_numpy_u64(d_points)
+        oracle.best_multiexp(sc[:4096], bs[:4096], cores)  # warm up
+        times = []
+        cpu_out = None
+        budget = time.perf_counter() + 30.0
+        while len(times) < 3 and time.perf_counter() < budget:
+            t1 = time.perf_counter()
+            cpu_out = oracle.best_multiexp(sc, bs, cores)
+            times.append(time.perf_counter() - t1)
+        tmed = sorted(times)[len(times) // 2]
+        cpu_c = oracle.window_c(n // cores)
+        cpu = {
+            "value": n * W / tmed,  # same unit as `value`: the job's n*W adds per second of CPU time
+            "unit": "G1-adds/s",
+            "pairs_per_s": n / tmed,
+            "cores": cores,
+            "kind": "port",
+            "sample": "full 2^%d-pair MSM, median of %d runs, %.3f s each; C restatement of best_multiexp "
+                      "(chunk = n/T per thread, c = %d unsigned windows), not the Rust binary" % (args.log_n, len(times), tmed, cpu_c),
+        }
+        parity = bool(np.array_equal(oracle.g1_to_affine(cpu_out), h2.g1_to_affine(result)))
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        adds = world * n * W * args.steps
+        accum_ms = stages.get("msm_accum")
+        roof = None
+        if accum_ms:
+            ach = MSM_BYTES_PER_PAIR * n / (accum_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                    "traffic": pmc_traffic("msm_2p%d" % args.log_n), "kernel": "msm_accum_kernel", "kernel_ms": accum_ms,
+                    "algorithmic_bytes_per_launch": MSM_BYTES_PER_PAIR * n}
+        out = {
+            "metric": "bn254_msm_g1_adds_per_sec",
+            "value": adds / elapsed,
+            "unit": "G1-adds/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32x8 (256-bit Montgomery integers)",
+            "data": "synthetic",
+            "config": {"workload": "bn254_g1_msm_2p%d_per_gpu" % args.log_n, "pairs_per_gpu": n, "window_bits": c, "windows": W,
+                       "signed_digits": True, "parallelism": "shard%d+allgather96B" % world},
+            "pairs_per_s": world * n * args.steps / elapsed,
+            "stage_ms": stages,
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "parity_vs_cpu": parity,
+            "ntt": ntt,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

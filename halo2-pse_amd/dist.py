@@ -1,0 +1,29 @@
+"""Multi-GPU MSM plumbing: one process per GPU, the pairs sharded by contiguous range (the
+partition best_multiexp itself uses across rayon threads, arithmetic.rs:137-152), one RCCL
+all-gather of the 96-byte Jacobian partials, then the left fold of arithmetic.rs:153 on every
+rank.  RCCL has no elliptic-curve reduction operator, so "reduce" = gather bytes + fold.
+torch.distributed is the transport only (backend "nccl" is RCCL on ROCm; "gloo" in CPU tests)."""
+import numpy as np
+
+
+def shard_range(n, rank, world):
+    """contiguous shard [lo, hi) of n pairs for `rank`; the last rank takes the remainder"""
+    per = n // world
+    lo = rank * per
+    hi = n if rank == world - 1 else lo + per
+    return lo, hi
+
+
+def allgather_fold(partial_xyz, h2, device=None, group=None):
+    """partial_xyz: (12,) uint64 Jacobian partial of this rank -> (12,) uint64 fold over all ranks,
+    identical on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    mine = torch.from_numpy(np.ascontiguousarray(partial_xyz, dtype=np.uint64).view(np.int64).copy())
+    if device is not None:
+        mine = mine.to(device)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine, group=group)
+    parts = np.stack([g.cpu().numpy().view(np.uint64) for g in gathered])
+    return h2.g1_fold(parts)

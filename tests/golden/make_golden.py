@@ -330,6 +330,14 @@ def main():
     out["gen_scalars_offset1000"] = fe_arr([gen_scalar(0x5EED0001, 1000 + i) for i in range(8)], R_MOD)
     out["gen_points_offset1000"] = pt_arr([gen_point(0x5EED0002, 1000 + i) for i in range(8)])
 
+    # the k = 6 SRS in the reference's on-disk format, ParamsKZG::write = write_custom(RawBytes)
+    # (poly/kzg/commitment.rs:142-157): k u32 LE | g | g_lagrange | g2 | s_g2.  The G2 points are not on
+    # this path (pairing stays on the CPU) and are written as zeros.
+    import struct
+    raw = struct.pack("<I", 6) + out["kzg_6_g"].tobytes() + out["kzg_6_g_lagrange"].tobytes() + bytes(256)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "kzg_6_params.rawbytes"), "wb") as f:
+        f.write(raw)
+
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

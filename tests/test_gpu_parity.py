@@ -234,3 +234,15 @@ def test_contract_violations_are_errors_not_crashes(h2):
         h2.best_fft(a, np.zeros(4, dtype=np.uint64), 3)
     with pytest.raises(AssertionError):
         h2.best_multiexp(np.zeros((2, 4), dtype=np.uint64), np.zeros((3, 8), dtype=np.uint64))
+
+
+def test_cpp_host_mirror(h2):
+    """halo2-pse_amd/host/halo2hip.hpp (C++ mirror of the reference's Rust API): its own test program,
+    written after poly/kzg/commitment.rs:361-384, must pass on the GPU."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "cpp", "test_host_mirror")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "host mirror tests ok" in r.stdout
