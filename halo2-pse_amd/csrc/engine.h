@@ -10,7 +10,7 @@
 #include <string>
 #include <vector>
 
-#include "ec.cuh"
+#include "ecu.cuh"
 
 namespace h2 {
 
@@ -44,8 +44,8 @@ struct TwiddleKey {
 };
 
 struct TwiddleTable {
-    Fe* lo = nullptr;  // omega^i, i < 2^lo_bits
-    Fe* hi = nullptr;  // omega^(i << lo_bits), i < 2^(log_n - lo_bits) (at least 1 entry)
+    Fu* lo = nullptr;  // omega^i, i < 2^lo_bits                                  (I-form limbs, fieldu.cuh)
+    Fu* hi = nullptr;  // omega^(i << lo_bits), i < 2^(log_n - lo_bits) (at least 1 entry)
     uint32_t lo_bits = 0;
 };
 

@@ -1,0 +1,294 @@
+// fieldu.cuh -- "unsaturated" BN254 field arithmetic for the hot kernels: 9 signed limbs of
+// 29 bits (value = sum l[i] * 2^(29 i)), lazily reduced, Montgomery radix 2^261.
+//
+// Why: on gfx950 every VALU instruction costs about the same (tools/instr_rate.hip), so a modular
+// multiply costs its instruction count.  With 29-bit limbs a whole column of 9 products plus 9
+// reduction products fits a 64-bit accumulator, so v_mad_i64_i32 accumulates with no carry
+// handling at all: ~250 instructions per multiply against ~535 for the saturated 8 x 32 CIOS of
+// field.cuh.  Additions and subtractions are 9 independent 32-bit ops with no carries and no
+// conditional subtraction; carries are propagated only where a bound below requires it.
+//
+// Forms (p = modulus, a = the field element):
+//   E-form  value == a * 2^256 (mod p)  -- what the reference stores (field.cuh's Fe, RawBytes)
+//   I-form  value == a * 2^261 (mod p)  -- Montgomery form for radix 2^261
+//   fu_mul(x, y) = x*y / 2^261 (mod p):  I*I -> I,  E*I -> E  (so NTT data stays in E-form against
+//   I-form twiddles, and E-form constants convert I-form results back for free).
+//
+// Bounds contract (checked by tests/cpp/test_fieldu.cpp on the host with H2_FU_CHECK):
+//   fu_mul needs 9 * max|a.l| * max|b.l| + 9 * 2^58 + 2^36 < 2^63  (e.g. |a.l| < 2^30, |b.l| < 2^29.9,
+//   or 2^29 x 2^30.4); its result has limbs 0..7 in [0, 2^29), a small signed top limb, and value in
+//   (a*b/2^261, a*b/2^261 + p).  fu_add / fu_sub are limb-wise on int32: callers keep |l| < 2^31.
+//   fu_norm propagates carries: limbs 0..7 back in [0, 2^29), value unchanged.
+#pragma once
+#include "field.cuh"
+
+namespace h2 {
+
+#define H2_MASK29 0x1fffffffu
+
+struct Fu {
+    int32_t l[9];
+};
+
+struct FqU {  // base field, 29-bit limbs
+    typedef FqP Sat;
+    static constexpr uint32_t P[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u,
+                                      0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    static constexpr uint32_t INV = 0x04866389u;   // -p^-1 mod 2^29
+    static constexpr uint32_t PINV = 0x1b799c77u;  //  p^-1 mod 2^29
+    static constexpr uint32_t ONE_I[9] = {0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x014c0419u, 0x0aa36fb9u,
+                                          0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};  // 2^261 mod p
+    static constexpr uint32_t ONE_E[9] = {0x058f0d9du, 0x1aea1c6eu, 0x11c2cf74u, 0x11d651ebu, 0x1462c0a7u,
+                                          0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u};  // 2^256 mod p
+    static constexpr uint32_t P16[9] = {0x07cfd470u, 0x10460b6cu, 0x072a34f0u, 0x0d522d0eu, 0x185d9781u,
+                                        0x0db40c0au, 0x0a6e1411u, 0x05c26340u, 0x030644e7u};    // 16 p
+};
+
+struct FrU {  // scalar field, 29-bit limbs
+    typedef FrP Sat;
+    static constexpr uint32_t P[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u,
+                                      0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    static constexpr uint32_t INV = 0x0fffffffu;
+    static constexpr uint32_t PINV = 0x10000001u;
+    static constexpr uint32_t ONE_I[9] = {0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu,
+                                          0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
+    static constexpr uint32_t ONE_E[9] = {0x0ffffffbu, 0x04b1a0e2u, 0x18334a6bu, 0x18ed2b3eu, 0x1462e36fu,
+                                          0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u};
+    static constexpr uint32_t P16[9] = {0x00000010u, 0x10fac9f8u, 0x05c2450fu, 0x1d090f37u, 0x185d2833u,
+                                        0x0db40c0au, 0x0a6e1411u, 0x05c26340u, 0x030644e7u};
+};
+
+#ifdef H2_FU_CHECK
+#include <assert.h>
+#define H2_FU_ASSERT(x) assert(x)
+#else
+#define H2_FU_ASSERT(x) ((void)0)
+#endif
+
+H2_HD Fu fu_zero() {
+    Fu o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.l[i] = 0;
+    return o;
+}
+
+template <class U>
+H2_HD Fu fu_const(const uint32_t c[9]) {
+    Fu o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.l[i] = (int32_t)c[i];
+    return o;
+}
+
+template <class U>
+H2_HD Fu fu_one_i() {
+    Fu o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.l[i] = (int32_t)U::ONE_I[i];
+    return o;
+}
+
+template <class U>
+H2_HD Fu fu_one_e() {
+    Fu o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.l[i] = (int32_t)U::ONE_E[i];
+    return o;
+}
+
+// all limbs exactly zero (used for the explicit identity marker, not a mod-p test)
+H2_HD bool fu_all_zero(const Fu& a) {
+    int32_t x = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) x |= a.l[i];
+    return x == 0;
+}
+
+// bits [pos, pos+29) of the 256-bit little-endian integer x (pos may be negative: low bits are zero)
+H2_HD uint32_t fe_bits29(const Fe& x, int pos) {
+    if (pos < 0) return (x.l[0] << (-pos)) & H2_MASK29;
+    int w = pos >> 5, sh = pos & 31;
+    uint64_t lo = x.l[w];
+    uint64_t hi = (w + 1 < 8) ? x.l[w + 1] : 0;
+    return (uint32_t)(((lo | (hi << 32)) >> sh) & H2_MASK29);
+}
+
+// Slice an Fe (canonical limbs of some integer v < 2^256) into 29-bit limbs of the same integer:
+// an E-form Fe stays E-form.  Limbs in [0, 2^29), top limb < 2^24.
+H2_HD Fu fu_slice(const Fe& x) {
+    Fu o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.l[i] = (int32_t)fe_bits29(x, 29 * i);
+    return o;
+}
+
+// E-form Fe -> I-form Fu for free: the limbs of 32*x (< 32 p, not reduced: fu_mul does not care)
+H2_HD Fu fu_from_ext(const Fe& x) {
+    Fu o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.l[i] = (int32_t)fe_bits29(x, 29 * i - 5);
+    return o;
+}
+
+H2_HD Fu fu_add(const Fu& a, const Fu& b) {
+    Fu o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        H2_FU_ASSERT((int64_t)a.l[i] + b.l[i] < ((int64_t)1 << 31) && (int64_t)a.l[i] + b.l[i] >= -((int64_t)1 << 31));
+        o.l[i] = a.l[i] + b.l[i];
+    }
+    return o;
+}
+
+H2_HD Fu fu_sub(const Fu& a, const Fu& b) {
+    Fu o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        H2_FU_ASSERT((int64_t)a.l[i] - b.l[i] < ((int64_t)1 << 31) && (int64_t)a.l[i] - b.l[i] >= -((int64_t)1 << 31));
+        o.l[i] = a.l[i] - b.l[i];
+    }
+    return o;
+}
+
+H2_HD Fu fu_dbl(const Fu& a) { return fu_add(a, a); }
+
+H2_HD Fu fu_neg(const Fu& a) {
+    Fu o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.l[i] = -a.l[i];
+    return o;
+}
+
+// carry propagation: limbs 0..7 -> [0, 2^29), top limb takes the (signed) rest
+H2_HD Fu fu_norm(const Fu& a) {
+    Fu o;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int32_t v = a.l[i] + c;
+        o.l[i] = (int32_t)((uint32_t)v & H2_MASK29);
+        c = v >> 29;
+    }
+    o.l[8] = a.l[8] + c;
+    return o;
+}
+
+// Montgomery product x*y/2^261 (mod p), product scanning with one 64-bit accumulator
+template <class U>
+H2_HD Fu fu_mul(const Fu& a, const Fu& b) {
+#ifdef H2_FU_CHECK
+    {
+        int64_t ma = 0, mb = 0;
+        for (int i = 0; i < 9; i++) {
+            int64_t x = a.l[i] < 0 ? -(int64_t)a.l[i] : a.l[i], y = b.l[i] < 0 ? -(int64_t)b.l[i] : b.l[i];
+            if (x > ma) ma = x;
+            if (y > mb) mb = y;
+        }
+        __int128 bound = (__int128)9 * ma * mb + ((__int128)9 << 58) + ((__int128)1 << 36);
+        assert(bound < ((__int128)1 << 63));
+    }
+#endif
+    int64_t acc = 0;
+    uint32_t m[9];
+    Fu r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (int64_t)a.l[i] * (int64_t)b.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (int64_t)m[i] * (int64_t)U::P[k - i];
+        m[k] = ((uint32_t)acc * U::INV) & H2_MASK29;
+        acc += (int64_t)m[k] * (int64_t)U::P[0];
+        acc >>= 29;  // exact: the low 29 bits are zero
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) acc += (int64_t)a.l[i] * (int64_t)b.l[k - i];
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) acc += (int64_t)m[i] * (int64_t)U::P[k - i];
+        r.l[k - 9] = (int32_t)((uint32_t)acc & H2_MASK29);
+        acc >>= 29;
+    }
+    r.l[8] = (int32_t)acc;
+    return r;
+}
+
+template <class U>
+H2_HD Fu fu_sqr(const Fu& a) {
+    return fu_mul<U>(a, a);
+}
+
+// Cheap necessary condition for value == k*p with |k| <= 8 (so for value == 0 mod p when
+// |value| < 8.5 p): value = k*p  =>  l0 * p^-1 == k (mod 2^29).  False positives ~2^-25.
+template <class U>
+H2_HD bool fu_maybe_zero_mod_p(const Fu& a) {
+    uint32_t t = ((uint32_t)a.l[0] * U::PINV + 8u) & H2_MASK29;
+    return t <= 16u;
+}
+
+// Pack a normalised Fu whose value is in [0, 2^256) into 8 x 32-bit words
+H2_HD void fu_pack(const Fu& a, uint32_t w[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        // word j = bits [32 j, 32 j + 32)
+        int lo_limb = (32 * j) / 29, sh = (32 * j) % 29;
+        uint64_t v = (uint64_t)(uint32_t)a.l[lo_limb] >> sh;
+        int have = 29 - sh;
+        if (lo_limb + 1 < 9) v |= (uint64_t)(uint32_t)a.l[lo_limb + 1] << have;
+        have += 29;
+        if (have < 32 && lo_limb + 2 < 9) v |= (uint64_t)(uint32_t)a.l[lo_limb + 2] << have;
+        w[j] = (uint32_t)v;
+    }
+}
+
+// Exact reduction: any Fu with |value| < 16 p -> the canonical integer in [0, p) as an Fe
+// (same residue, so the form -- E or I -- is unchanged).  Not on the hot path.
+template <class U>
+H2_HD Fe fu_canon(const Fu& a) {
+    Fu cur = fu_norm(fu_add(a, fu_const<U>(U::P16)));  // now in (0, 32 p) < 2^260
+    // conditional subtractions of 16p, 8p, 4p, 2p, p
+    for (int sh = 4; sh >= 0; sh--) {
+        Fu kp;
+        uint64_t c = 0;
+        for (int i = 0; i < 9; i++) {
+            uint64_t v = ((uint64_t)U::P[i] << sh) + c;
+            kp.l[i] = (int32_t)(v & H2_MASK29);
+            c = v >> 29;
+        }
+        kp.l[8] += (int32_t)(c << 29);
+        Fu d = fu_norm(fu_sub(cur, kp));
+        if (d.l[8] >= 0) cur = d;  // normalised: the sign of the value is the sign of the top limb
+    }
+    uint32_t w[8];
+    fu_pack(cur, w);
+    Fe out;
+#pragma unroll
+    for (int j = 0; j < 8; j++) out.l[j] = w[j];
+    return out;
+}
+
+// Exact test value == 0 (mod p) for |value| < 8.5 p: cheap filter first, exact reduction on a hit
+template <class U>
+H2_HD bool fu_is_zero_mod_p(const Fu& a) {
+    if (!fu_maybe_zero_mod_p<U>(a)) return false;
+    return fe_is_zero(fu_canon<U>(a));
+}
+
+// (x * c) / 2^261 reduced to the canonical integer in [0, p), for |x| < 16 p and c normalised
+// non-negative (< 2^256).  With c an E-form constant and x I-form this is the E-form result the
+// reference stores; with x E-form and c I-form likewise.  x + 16p > 0 makes the Montgomery
+// result land in [0, 1.2 p): one conditional subtraction finishes the job.
+template <class U>
+H2_HD Fe fu_mul_canon(const Fu& x, const Fu& c) {
+    typedef typename U::Sat P;
+    Fu xp = fu_norm(fu_add(x, fu_const<U>(U::P16)));
+    Fu r = fu_mul<U>(xp, c);  // in [0, 32p * 2^256 / 2^261 + p) = [0, 2p)
+    uint32_t w[8];
+    fu_pack(r, w);
+    Fe o;
+    fe_cond_sub<P>(o, w);
+    return o;
+}
+
+}  // namespace h2

@@ -86,21 +86,21 @@ struct HeavyChunk {
     uint32_t begin, end;
 };
 
-__device__ __forceinline__ Affine load_signed(const Affine* __restrict__ bases, uint32_t v) {
+// one bucket-accumulation step: acc += (+/-) bases[index], in the unsaturated arithmetic of ecu.cuh
+__device__ __forceinline__ void accum_signed(XYZZu& acc, const Affine* __restrict__ bases, uint32_t v) {
     Affine p = bases[v & 0x7fffffffu];
-    if (v >> 31) p.y = fe_neg<Q>(p.y);
-    return p;
+    xyzzu_add_affine(acc, p, (v >> 31) != 0);
 }
 
 // K2: one lane per bucket
 __global__ void __launch_bounds__(256) msm_accum_kernel(const Affine* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                         const uint32_t* __restrict__ start, uint32_t n_buckets, uint32_t heavy_t,
-                                                        uint32_t chunk, XYZZ* __restrict__ buckets, uint32_t* __restrict__ heavy_counts,
+                                                        uint32_t chunk, XYZZu* __restrict__ buckets, uint32_t* __restrict__ heavy_counts,
                                                         HeavyBucket* __restrict__ heavy_buckets, HeavyChunk* __restrict__ heavy_chunks) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_buckets) return;
     uint32_t s = start[b], e = start[b + 1];
-    XYZZ acc = xyzz_identity();
+    XYZZu acc = xyzzu_identity();
     if (e - s > heavy_t) {
         uint32_t nch = (e - s + chunk - 1) / chunk;
         uint32_t slot = atomicAdd(&heavy_counts[1], nch);
@@ -112,22 +112,19 @@ __global__ void __launch_bounds__(256) msm_accum_kernel(const Affine* __restrict
             heavy_chunks[slot + q] = ch;
         }
     } else {
-        for (uint32_t i = s; i < e; i++) {
-            Affine p = load_signed(bases, vals[i]);
-            xyzz_add_mixed(acc, p);
-        }
+        for (uint32_t i = s; i < e; i++) accum_signed(acc, bases, vals[i]);
     }
     buckets[b] = acc;
 }
 
-// tree-sum 256 XYZZ values through LDS; result valid in thread 0
-__device__ __forceinline__ XYZZ block_tree_sum(XYZZ v, XYZZ* sh) {
+// tree-sum 256 XYZZu values through LDS; result valid in thread 0
+__device__ __forceinline__ XYZZu block_tree_sum(XYZZu v, XYZZu* sh) {
     sh[threadIdx.x] = v;
     __syncthreads();
     for (uint32_t stride = blockDim.x >> 1; stride >= 1; stride >>= 1) {
         if (threadIdx.x < stride) {
-            XYZZ a = sh[threadIdx.x];
-            xyzz_add(a, sh[threadIdx.x + stride]);
+            XYZZu a = sh[threadIdx.x];
+            xyzzu_add(a, sh[threadIdx.x + stride]);
             sh[threadIdx.x] = a;
         }
         __syncthreads();
@@ -138,17 +135,14 @@ __device__ __forceinline__ XYZZ block_tree_sum(XYZZ v, XYZZ* sh) {
 // K2h-1: workgroups stride over the chunk list; every wave exits once its index passes the count
 __global__ void __launch_bounds__(256) msm_heavy_chunk_kernel(const Affine* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                               const uint32_t* __restrict__ heavy_counts, const HeavyChunk* __restrict__ heavy_chunks,
-                                                              XYZZ* __restrict__ chunk_sums) {
-    __shared__ XYZZ sh[256];
+                                                              XYZZu* __restrict__ chunk_sums) {
+    __shared__ XYZZu sh[256];
     const uint32_t total = heavy_counts[1];
     for (uint32_t ci = blockIdx.x; ci < total; ci += gridDim.x) {
         HeavyChunk ch = heavy_chunks[ci];
-        XYZZ acc = xyzz_identity();
-        for (uint32_t i = ch.begin + threadIdx.x; i < ch.end; i += blockDim.x) {
-            Affine p = load_signed(bases, vals[i]);
-            xyzz_add_mixed(acc, p);
-        }
-        XYZZ r = block_tree_sum(acc, sh);
+        XYZZu acc = xyzzu_identity();
+        for (uint32_t i = ch.begin + threadIdx.x; i < ch.end; i += blockDim.x) accum_signed(acc, bases, vals[i]);
+        XYZZu r = block_tree_sum(acc, sh);
         if (threadIdx.x == 0) chunk_sums[ci] = r;
         __syncthreads();
     }
@@ -156,30 +150,30 @@ __global__ void __launch_bounds__(256) msm_heavy_chunk_kernel(const Affine* __re
 
 // K2h-2: one workgroup per over-full bucket sums its chunk sums into the bucket
 __global__ void __launch_bounds__(256) msm_heavy_final_kernel(const uint32_t* __restrict__ heavy_counts, const HeavyBucket* __restrict__ heavy_buckets,
-                                                              const XYZZ* __restrict__ chunk_sums, XYZZ* __restrict__ buckets) {
-    __shared__ XYZZ sh[256];
+                                                              const XYZZu* __restrict__ chunk_sums, XYZZu* __restrict__ buckets) {
+    __shared__ XYZZu sh[256];
     const uint32_t total = heavy_counts[0];
     for (uint32_t hi = blockIdx.x; hi < total; hi += gridDim.x) {
         HeavyBucket h = heavy_buckets[hi];
-        XYZZ acc = xyzz_identity();
-        for (uint32_t q = threadIdx.x; q < h.n_chunks; q += blockDim.x) xyzz_add(acc, chunk_sums[h.first_chunk + q]);
-        XYZZ r = block_tree_sum(acc, sh);
+        XYZZu acc = xyzzu_identity();
+        for (uint32_t q = threadIdx.x; q < h.n_chunks; q += blockDim.x) xyzzu_add(acc, chunk_sums[h.first_chunk + q]);
+        XYZZu r = block_tree_sum(acc, sh);
         if (threadIdx.x == 0) buckets[h.bucket] = r;
         __syncthreads();
     }
 }
 
 // K3 level 1: lane t of window w folds buckets [t*s1, (t+1)*s1): run = sum B_i, acc = sum (i - t*s1 + 1) B_i
-__global__ void __launch_bounds__(256) msm_reduce1_kernel(const XYZZ* __restrict__ buckets, uint32_t n_seg_total, uint32_t log_s1,
-                                                          XYZZ* __restrict__ acc_out, XYZZ* __restrict__ run_out) {
+__global__ void __launch_bounds__(256) msm_reduce1_kernel(const XYZZu* __restrict__ buckets, uint32_t n_seg_total, uint32_t log_s1,
+                                                          XYZZu* __restrict__ acc_out, XYZZu* __restrict__ run_out) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_seg_total) return;
     const uint32_t s1 = 1u << log_s1;
-    const XYZZ* seg = buckets + ((size_t)t << log_s1);
-    XYZZ run = xyzz_identity(), acc = xyzz_identity();
+    const XYZZu* seg = buckets + ((size_t)t << log_s1);
+    XYZZu run = xyzzu_identity(), acc = xyzzu_identity();
     for (uint32_t i = s1; i-- > 0;) {
-        xyzz_add(run, seg[i]);
-        xyzz_add(acc, run);
+        xyzzu_add(run, seg[i]);
+        xyzzu_add(acc, run);
     }
     acc_out[t] = acc;
     run_out[t] = run;
@@ -187,32 +181,32 @@ __global__ void __launch_bounds__(256) msm_reduce1_kernel(const XYZZ* __restrict
 
 // K3 level 2: one workgroup per window over its m1 (acc, run) pairs:
 //   window sum = sum_t ACC[t] + s1 * sum_t t * RUN[t]
-__global__ void __launch_bounds__(256) msm_reduce2_kernel(const XYZZ* __restrict__ acc_in, const XYZZ* __restrict__ run_in, uint32_t m1,
+__global__ void __launch_bounds__(256) msm_reduce2_kernel(const XYZZu* __restrict__ acc_in, const XYZZu* __restrict__ run_in, uint32_t m1,
                                                           uint32_t log_s1, XYZZ* __restrict__ window_sums) {
-    __shared__ XYZZ sh[256];
+    __shared__ XYZZu sh[256];
     const uint32_t w = blockIdx.x;
-    const XYZZ* A = acc_in + (size_t)w * m1;
-    const XYZZ* Rn = run_in + (size_t)w * m1;
+    const XYZZu* A = acc_in + (size_t)w * m1;
+    const XYZZu* Rn = run_in + (size_t)w * m1;
     const uint32_t s2 = (m1 + 255) / 256;
     const uint32_t lo = threadIdx.x * s2;
-    XYZZ v = xyzz_identity();
+    XYZZu v = xyzzu_identity();
     if (lo < m1) {
         uint32_t hi = lo + s2 < m1 ? lo + s2 : m1;
-        XYZZ a = xyzz_identity(), run2 = xyzz_identity(), acc2 = xyzz_identity();
+        XYZZu a = xyzzu_identity(), run2 = xyzzu_identity(), acc2 = xyzzu_identity();
         for (uint32_t t = hi; t-- > lo;) {
-            xyzz_add(a, A[t]);
-            xyzz_add(run2, Rn[t]);
-            if (t != lo) xyzz_add(acc2, run2);
+            xyzzu_add(a, A[t]);
+            xyzzu_add(run2, Rn[t]);
+            if (t != lo) xyzzu_add(acc2, run2);
         }
         // sum_{t in [lo,hi)} t*RUN[t] = acc2 + lo*run2
-        XYZZ wsum = xyzz_mul_small(run2, lo);
-        xyzz_add(wsum, acc2);
-        for (uint32_t k = 0; k < log_s1; k++) wsum = xyzz_double(wsum);
-        xyzz_add(wsum, a);
+        XYZZu wsum = xyzzu_mul_small(run2, lo);
+        xyzzu_add(wsum, acc2);
+        for (uint32_t k = 0; k < log_s1; k++) wsum = xyzzu_double(wsum);
+        xyzzu_add(wsum, a);
         v = wsum;
     }
-    XYZZ r = block_tree_sum(v, sh);
-    if (threadIdx.x == 0) window_sums[w] = r;
+    XYZZu r = block_tree_sum(v, sh);
+    if (threadIdx.x == 0) window_sums[w] = xyzzu_to_ext(r);  // canonical E-form for the host Horner
 }
 
 static uint32_t g_window_override = 0;
@@ -284,24 +278,25 @@ static int msm_device_chunk(Ctx* c, const Fe* d_scalars, const Affine* d_bases, 
     size_t o_keys0 = carve(E * 4), o_keys1 = carve(E * 4), o_vals0 = carve(E * 4), o_vals1 = carve(E * 4);
     size_t o_cub = carve(cub_bytes);
     size_t o_start = carve(((size_t)n_buckets + 2) * 4);
-    size_t o_buckets = carve((size_t)n_buckets * sizeof(XYZZ));
-    size_t o_acc = carve((size_t)p.W * m1 * sizeof(XYZZ)), o_run = carve((size_t)p.W * m1 * sizeof(XYZZ));
+    size_t o_buckets = carve((size_t)n_buckets * sizeof(XYZZu));
+    size_t o_acc = carve((size_t)p.W * m1 * sizeof(XYZZu)), o_run = carve((size_t)p.W * m1 * sizeof(XYZZu));
     size_t o_wsum = carve((size_t)p.W * sizeof(XYZZ));
     size_t o_hcnt = carve(16);
     size_t o_hb = carve(max_heavy * sizeof(HeavyBucket)), o_hc = carve(max_chunks * sizeof(HeavyChunk));
-    size_t o_hs = carve(max_chunks * sizeof(XYZZ));
+    size_t o_hs = carve(max_chunks * sizeof(XYZZu));
     int rc = c->msm_ws.ensure(off);
     if (rc) return rc;
     char* base = (char*)c->msm_ws.p;
     uint32_t *keys0 = (uint32_t*)(base + o_keys0), *keys1 = (uint32_t*)(base + o_keys1);
     uint32_t *vals0 = (uint32_t*)(base + o_vals0), *vals1 = (uint32_t*)(base + o_vals1);
     uint32_t* start = (uint32_t*)(base + o_start);
-    XYZZ* buckets = (XYZZ*)(base + o_buckets);
-    XYZZ *accs = (XYZZ*)(base + o_acc), *runs = (XYZZ*)(base + o_run), *wsum = (XYZZ*)(base + o_wsum);
+    XYZZu* buckets = (XYZZu*)(base + o_buckets);
+    XYZZu *accs = (XYZZu*)(base + o_acc), *runs = (XYZZu*)(base + o_run);
+    XYZZ* wsum = (XYZZ*)(base + o_wsum);
     uint32_t* hcnt = (uint32_t*)(base + o_hcnt);
     HeavyBucket* hb = (HeavyBucket*)(base + o_hb);
     HeavyChunk* hc = (HeavyChunk*)(base + o_hc);
-    XYZZ* hs = (XYZZ*)(base + o_hs);
+    XYZZu* hs = (XYZZu*)(base + o_hs);
 
     rc = c->ws_acquire(s);
     if (rc) return rc;

@@ -17,40 +17,50 @@
 #include <string.h>
 
 #include "engine.h"
+#include "fieldu.cuh"
 
 namespace h2 {
 
 struct NttPass {
     const Fe* src;
     Fe* dst;
-    const Fe* tw_lo;
-    const Fe* tw_hi;
+    const Fu* tw_lo;
+    const Fu* tw_hi;
     uint64_t in_len;
     uint32_t log_n, log_m, s, log_j, lo_bits;
     uint32_t first, in_scale, out_scale;
     uint32_t n_prev;
     uint32_t prev_s[4];
-    Fe in3[3], out3[3];
+    Fu in3[3], out3[3];  // I-form constants
 };
 
 #define NTT_THREADS 256
 
-__device__ __forceinline__ Fe tw_pow(const NttPass& p, uint64_t e) {
+// Arithmetic: data stays in the reference's E-form (value == a * 2^256 mod r) as lazily reduced
+// 9 x 29-bit limbs (fieldu.cuh); twiddles and scale constants are I-form, so every
+// fu_mul(data, twiddle) is again E-form and the last multiply of a pass doubles as the exact
+// reduction back to canonical limbs (fu_mul_canon).
+
+__device__ __forceinline__ Fu tw_pow(const NttPass& p, uint64_t e) {
     uint32_t lo = (uint32_t)(e & ((1ull << p.lo_bits) - 1));
     uint64_t hi = e >> p.lo_bits;
-    Fe a = p.tw_lo[lo];
-    if (hi) a = fe_mul<FrP>(a, p.tw_hi[hi]);
+    Fu a = p.tw_lo[lo];
+    if (hi) a = fu_mul<FrU>(a, p.tw_hi[hi]);
     return a;
 }
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t k, uint32_t s) { return __brev(k) >> (32 - s); }
 
-// R-point DFT (DIF, output bit-reversed inside the column) on J columns held in LDS as x[col*R + r]
-__device__ __forceinline__ void dft_lds(Fe* x, const Fe* wtab, uint32_t s, uint32_t log_j) {
+// R-point DFT on J columns held in LDS as x[col*R + bitrev(r)] on entry, x[col*R + k] on exit
+// (decimation in time).  Stage 1 has unit twiddles; every later stage multiplies (also by w^0 = 1,
+// which keeps |value| growing by at most ~1.3 r per stage instead of doubling); limbs are
+// re-normalised after every even stage, which keeps every fu_mul operand below 2^30.
+__device__ __forceinline__ void dft_lds(Fu* x, const Fu* wtab, uint32_t s, uint32_t log_j) {
     const uint32_t R = 1u << s;
     const uint32_t nbf = (R << log_j) >> 1;
-    uint32_t log_h = s - 1;
-    for (uint32_t h = R >> 1; h >= 1; h >>= 1, log_h--) {
+    for (uint32_t log_h = 0; log_h < s; log_h++) {
+        const uint32_t h = 1u << log_h;
+        const bool norm = (log_h & 1) != 0;
         for (uint32_t bf = threadIdx.x; bf < nbf; bf += NTT_THREADS) {
             uint32_t col = bf >> (s - 1);
             uint32_t i = bf & ((R >> 1) - 1);
@@ -58,36 +68,39 @@ __device__ __forceinline__ void dft_lds(Fe* x, const Fe* wtab, uint32_t s, uint3
             uint32_t blk = i >> log_h;
             uint32_t i0 = (col << s) + (blk << (log_h + 1)) + off;
             uint32_t i1 = i0 + h;
-            Fe a = x[i0], b = x[i1];
-            x[i0] = fe_add<FrP>(a, b);
-            Fe d = fe_sub<FrP>(a, b);
-            if (off) d = fe_mul<FrP>(d, wtab[off << (s - 1 - log_h)]);
-            x[i1] = d;
+            Fu a = x[i0], t = x[i1];
+            if (log_h) t = fu_mul<FrU>(t, wtab[off << (s - 1 - log_h)]);
+            Fu u = fu_add(a, t), v = fu_sub(a, t);
+            if (norm) {
+                u = fu_norm(u);
+                v = fu_norm(v);
+            }
+            x[i0] = u;
+            x[i1] = v;
         }
         __syncthreads();
-        if (h == 1) break;
     }
 }
 
-__device__ __forceinline__ Fe ntt_load(const NttPass& p, uint64_t gi) {
+__device__ __forceinline__ Fu ntt_load(const NttPass& p, uint64_t gi) {
     if (p.first) {
-        if (gi >= p.in_len) return fe_zero<FrP>();
-        Fe v = p.src[gi];
+        if (gi >= p.in_len) return fu_zero();
+        Fu v = fu_slice(p.src[gi]);
         if (p.in_scale) {
             uint32_t m = (uint32_t)(gi % 3);
-            if (m) v = fe_mul<FrP>(v, p.in3[m]);
+            if (m) v = fu_mul<FrU>(v, p.in3[m]);
         }
         return v;
     }
-    return p.src[gi];
+    return fu_slice(p.src[gi]);
 }
 
 extern __shared__ __align__(16) unsigned char ntt_lds_raw[];
 
 __global__ void __launch_bounds__(NTT_THREADS) ntt_strided_kernel(NttPass p) {
-    Fe* x = reinterpret_cast<Fe*>(ntt_lds_raw);
+    Fu* x = reinterpret_cast<Fu*>(ntt_lds_raw);
     const uint32_t R = 1u << p.s, J = 1u << p.log_j;
-    Fe* wtab = x + (R << p.log_j);
+    Fu* wtab = x + (R << p.log_j);
     const uint32_t log_l = p.log_m - p.s;                 // L = M/R columns per block
     const uint32_t log_gpb = log_l - p.log_j;             // column groups per block
     const uint64_t u = blockIdx.x;
@@ -96,24 +109,22 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_strided_kernel(NttPass p) {
     for (uint32_t i = threadIdx.x; i < (R >> 1); i += NTT_THREADS) wtab[i] = tw_pow(p, (uint64_t)i << (p.log_n - p.s));
     for (uint32_t idx = threadIdx.x; idx < (R << p.log_j); idx += NTT_THREADS) {
         uint32_t r = idx >> p.log_j, jj = idx & (J - 1);
-        x[(jj << p.s) + r] = ntt_load(p, base + ((uint64_t)r << log_l) + lo0 + jj);
+        x[(jj << p.s) + bitrev(r, p.s)] = ntt_load(p, base + ((uint64_t)r << log_l) + lo0 + jj);
     }
     __syncthreads();
     dft_lds(x, wtab, p.s, p.log_j);
     for (uint32_t idx = threadIdx.x; idx < (R << p.log_j); idx += NTT_THREADS) {
         uint32_t k = idx >> p.log_j, jj = idx & (J - 1);
-        Fe v = x[(jj << p.s) + bitrev(k, p.s)];
         uint64_t lo = lo0 + jj;
         uint64_t e = ((uint64_t)k * lo) << (p.log_n - p.log_m);  // w_M^(k*lo) = omega^((N/M)*k*lo)
-        if (e) v = fe_mul<FrP>(v, tw_pow(p, e));
-        p.dst[base + ((uint64_t)k << log_l) + lo] = v;
+        p.dst[base + ((uint64_t)k << log_l) + lo] = fu_mul_canon<FrU>(x[(jj << p.s) + k], tw_pow(p, e));
     }
 }
 
 __global__ void __launch_bounds__(NTT_THREADS) ntt_final_kernel(NttPass p) {
-    Fe* x = reinterpret_cast<Fe*>(ntt_lds_raw);
+    Fu* x = reinterpret_cast<Fu*>(ntt_lds_raw);
     const uint32_t R = 1u << p.s, J = 1u << p.log_j;
-    Fe* wtab = x + (R << p.log_j);
+    Fu* wtab = x + (R << p.log_j);
     const uint64_t g = blockIdx.x;
     for (uint32_t i = threadIdx.x; i < (R >> 1); i += NTT_THREADS) wtab[i] = tw_pow(p, (uint64_t)i << (p.log_n - p.s));
     for (uint32_t idx = threadIdx.x; idx < (R << p.log_j); idx += NTT_THREADS) {
@@ -124,36 +135,42 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_final_kernel(NttPass p) {
             bi = (bi << p.prev_s[t]) | (v & ((1ull << p.prev_s[t]) - 1));
             v >>= p.prev_s[t];
         }
-        x[(jj << p.s) + r] = ntt_load(p, (bi << p.s) + r);
+        x[(jj << p.s) + bitrev(r, p.s)] = ntt_load(p, (bi << p.s) + r);
     }
     __syncthreads();
     dft_lds(x, wtab, p.s, p.log_j);
     const uint32_t log_nb = p.log_n - p.s;
+    const Fu one_i = fu_one_i<FrU>();
     for (uint32_t idx = threadIdx.x; idx < (R << p.log_j); idx += NTT_THREADS) {
         uint32_t k = idx >> p.log_j, jj = idx & (J - 1);
-        Fe v = x[(jj << p.s) + bitrev(k, p.s)];
         uint64_t oi = ((uint64_t)k << log_nb) + (g << p.log_j) + jj;
-        if (p.out_scale) v = fe_mul<FrP>(v, p.out3[oi % 3]);
-        p.dst[oi] = v;
+        Fu c = p.out_scale ? p.out3[oi % 3] : one_i;
+        p.dst[oi] = fu_mul_canon<FrU>(x[(jj << p.s) + k], c);
     }
 }
 
 // n = 1: best_fft is the identity; only the fused scales apply
 __global__ void ntt_n1_kernel(NttPass p) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        Fe v = ntt_load(p, 0);
-        if (p.out_scale) v = fe_mul<FrP>(v, p.out3[0]);
-        p.dst[0] = v;
+        Fu v = ntt_load(p, 0);
+        p.dst[0] = fu_mul_canon<FrU>(v, p.out_scale ? p.out3[0] : fu_one_i<FrU>());
     }
 }
 
-__global__ void twiddle_build_kernel(Fe omega, Fe* lo, uint32_t n_lo, Fe* hi, uint32_t n_hi, uint32_t lo_bits) {
+// E-form canonical Fe -> I-form canonical limbs (x * 2^5 mod r), sliced
+__host__ __device__ __forceinline__ Fu fu_i_from_fe(const Fe& x) {
+    Fe t = x;
+    for (int k = 0; k < 5; k++) t = fe_dbl<FrP>(t);
+    return fu_slice(t);
+}
+
+__global__ void twiddle_build_kernel(Fe omega, Fu* lo, uint32_t n_lo, Fu* hi, uint32_t n_hi, uint32_t lo_bits) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_lo) {
-        lo[i] = fe_pow_u64<FrP>(omega, i);
+        lo[i] = fu_i_from_fe(fe_pow_u64<FrP>(omega, i));
     } else if (i < n_lo + n_hi) {
         uint32_t j = i - n_lo;
-        hi[j] = fe_pow_u64<FrP>(omega, (uint64_t)j << lo_bits);
+        hi[j] = fu_i_from_fe(fe_pow_u64<FrP>(omega, (uint64_t)j << lo_bits));
     }
 }
 
@@ -169,8 +186,8 @@ static int get_twiddles(Ctx* c, const Fe& omega, uint32_t log_n, hipStream_t s, 
     TwiddleTable t;
     t.lo_bits = log_n < 10 ? log_n : 10;
     uint32_t n_lo = 1u << t.lo_bits, n_hi = 1u << (log_n - t.lo_bits);
-    H2_CHECK(hipMalloc((void**)&t.lo, (size_t)n_lo * sizeof(Fe)));
-    H2_CHECK(hipMalloc((void**)&t.hi, (size_t)n_hi * sizeof(Fe)));
+    H2_CHECK(hipMalloc((void**)&t.lo, (size_t)n_lo * sizeof(Fu)));
+    H2_CHECK(hipMalloc((void**)&t.hi, (size_t)n_hi * sizeof(Fu)));
     uint32_t total = n_lo + n_hi;
     hipLaunchKernelGGL(twiddle_build_kernel, dim3((total + 255) / 256), dim3(256), 0, s, omega, t.lo, n_lo, t.hi, n_hi, t.lo_bits);
     H2_CHECK(hipGetLastError());
@@ -214,8 +231,8 @@ int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttSca
         p.out_scale = sc->out_scale;
         if (sc->in_len) p.in_len = sc->in_len;
         for (int i = 0; i < 3; i++) {
-            p.in3[i] = sc->in3[i];
-            p.out3[i] = sc->out3[i];
+            p.in3[i] = fu_i_from_fe(sc->in3[i]);
+            p.out3[i] = fu_i_from_fe(sc->out3[i]);
         }
     }
     int rc0 = c->ws_acquire(s);
@@ -264,7 +281,7 @@ int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttSca
             uint32_t log_l = log_m - p.s;
             p.log_j = log_l < 2 ? log_l : 2;
         }
-        size_t lds = (((size_t)1 << (p.s + p.log_j)) + ((size_t)1 << p.s) / 2 + 1) * sizeof(Fe);
+        size_t lds = (((size_t)1 << (p.s + p.log_j)) + ((size_t)1 << p.s) / 2 + 1) * sizeof(Fu);
         uint64_t grid = 1ull << (log_n - p.s - p.log_j);
         if (grid > 0x7fffffffull) {
             set_error("ntt: grid too large");

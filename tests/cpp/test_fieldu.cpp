@@ -1,0 +1,221 @@
+// Host-side fuzz of csrc/fieldu.cuh + csrc/ecu.cuh (the unsaturated arithmetic the kernels run)
+// against csrc/field.cuh + csrc/ec.cuh (the saturated arithmetic, itself checked against the oracle
+// by tests/test_abi.py).  Built with -DH2_FU_CHECK so every fu_mul / fu_add asserts its limb bounds.
+// No GPU needed: the same H2_HD source compiles for the host.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../halo2-pse_amd/csrc/ecu.cuh"
+
+using namespace h2;
+
+static uint64_t rs = 0x1234567;
+static uint64_t rnd() {
+    rs += 0x9E3779B97F4A7C15ULL;
+    uint64_t x = rs;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+static int failures = 0;
+#define CHECK(c)                                                   \
+    do {                                                           \
+        if (!(c)) {                                                \
+            if (failures < 20) printf("FAIL line %d: %s\n", __LINE__, #c); \
+            failures++;                                            \
+        }                                                          \
+    } while (0)
+
+template <class P>
+static Fe rand_fe(int kind) {
+    Fe a;
+    for (int j = 0; j < 8; j++) a.l[j] = (uint32_t)rnd();
+    a.l[7] &= 0x1fffffff;
+    if (kind == 1) a = fe_zero<P>();
+    if (kind == 2) {  // p - 1
+        a = fe_zero<P>();
+        a.l[0] = 1;
+        a = fe_neg<P>(a);
+    }
+    if (kind == 3) {
+        a = fe_zero<P>();
+        a.l[0] = 1;
+    }
+    if (!fe_is_canonical<P>(a)) a.l[7] = 0;
+    return a;
+}
+
+template <class U>
+static void test_field(const char* name) {
+    typedef typename U::Sat P;
+    const Fu one_e = fu_one_e<U>(), one_i = fu_one_i<U>();
+    for (int it = 0; it < 20000; it++) {
+        Fe a = rand_fe<P>(it < 40 ? it % 4 : 0), b = rand_fe<P>(it < 40 ? (it / 4) % 4 : 0);
+        CHECK(fe_eq(fu_canon<U>(fu_slice(a)), a));
+        Fe a32 = a;
+        for (int k = 0; k < 5; k++) a32 = fe_dbl<P>(a32);
+        CHECK(fe_eq(fu_canon<U>(fu_mul<U>(fu_from_ext(a), one_i)), a32));  // 32a < 32p is outside fu_canon's range until reduced
+        Fe want = fe_mul<P>(a, b);
+        // I * I -> I, then back to E-form through the E-form one
+        Fu ri = fu_mul<U>(fu_from_ext(a), fu_from_ext(b));
+        CHECK(fe_eq(fu_mul_canon<U>(ri, one_e), want));
+        // E * I -> E
+        Fu bi = fu_mul<U>(fu_from_ext(b), one_i);
+        CHECK(fe_eq(fu_mul_canon<U>(fu_slice(a), bi), want));
+        CHECK(fe_eq(fu_canon<U>(fu_mul<U>(fu_slice(a), bi)), want));
+        // linear ops on loose values
+        Fu sa = fu_slice(a), sb = fu_slice(b);
+        CHECK(fe_eq(fu_canon<U>(fu_add(sa, sb)), fe_add<P>(a, b)));
+        CHECK(fe_eq(fu_canon<U>(fu_sub(sa, sb)), fe_sub<P>(a, b)));
+        CHECK(fe_eq(fu_canon<U>(fu_neg(sa)), fe_neg<P>(a)));
+        CHECK(fe_eq(fu_canon<U>(fu_norm(fu_sub(fu_sub(sa, sb), fu_dbl(sb)))), fe_sub<P>(fe_sub<P>(a, b), fe_dbl<P>(b))));
+        // a product of two differences (signed limbs through fu_mul)
+        Fu d1 = fu_sub(sa, sb), d2 = fu_sub(fu_mul<U>(sb, one_i), sa);  // d2 = b_E - a_E
+        Fe w2 = fe_mul<P>(fe_sub<P>(a, b), fe_sub<P>(b, a));
+        Fu d2i = fu_norm(fu_sub(fu_mul<U>(fu_from_ext(b), one_i), fu_mul<U>(fu_from_ext(a), one_i)));  // I-form (b - a)
+        CHECK(fe_eq(fu_canon<U>(fu_mul<U>(d1, d2i)), w2));
+        (void)d2;
+        // zero test
+        Fu z = fu_sub(sa, sa);
+        CHECK(fu_is_zero_mod_p<U>(z));
+        if (!fe_is_zero(a)) CHECK(!fu_is_zero_mod_p<U>(fu_norm(sa)) || false);
+    }
+    // k*p and k*p + 1 for |k| <= 8
+    Fu pf = fu_const<U>(U::P);
+    for (int k = -8; k <= 8; k++) {
+        Fu v = fu_zero();
+        for (int j = 0; j < (k < 0 ? -k : k); j++) v = fu_norm(k < 0 ? fu_sub(v, pf) : fu_add(v, pf));
+        v = fu_norm(v);
+        CHECK(fu_is_zero_mod_p<U>(v));
+        Fu v1 = v;
+        v1.l[0] += 1;
+        CHECK(!fu_is_zero_mod_p<U>(v1));
+        Fu v2 = v;
+        v2.l[3] += 5;
+        CHECK(!fu_is_zero_mod_p<U>(v2));
+    }
+    printf("%s field fuzz done, failures so far %d\n", name, failures);
+}
+
+static bool same_point(const XYZZu& u, const XYZZ& s) {
+    Affine a = xyzz_to_affine(xyzzu_to_ext(u)), b = xyzz_to_affine(s);
+    return fe_eq(a.x, b.x) && fe_eq(a.y, b.y);
+}
+
+static void test_ec() {
+    // points: multiples of the generator (1, 2)
+    Affine g;
+    g.x = fe_from_u64<Q>(1);
+    g.y = fe_from_u64<Q>(2);
+    const int NP = 48;
+    std::vector<Affine> pts;
+    XYZZ cur = xyzz_identity();
+    for (int i = 0; i < NP; i++) {
+        xyzz_add_mixed(cur, g);
+        XYZZ big = cur;
+        for (int k = 0; k < 40 + i; k++) big = xyzz_double(big);  // spread the x coordinates
+        xyzz_add(big, cur);
+        pts.push_back(xyzz_to_affine(big));
+        CHECK(affine_on_curve(pts.back()));
+    }
+    Affine ident;
+    ident.x = fe_zero<Q>();
+    ident.y = fe_zero<Q>();
+    // random signed accumulation chains, with repeats (doubling), inverses (identity) and identity inputs
+    for (int chain = 0; chain < 60; chain++) {
+        XYZZ s = xyzz_identity();
+        XYZZu u = xyzzu_identity();
+        int len = 1 + (int)(rnd() % 300);
+        int last = 0;
+        bool lastneg = false;
+        for (int i = 0; i < len; i++) {
+            int r = (int)(rnd() % 100);
+            int idx = (int)(rnd() % NP);
+            bool neg = rnd() & 1;
+            if (r < 5) { idx = last; neg = lastneg; }        // same point again -> doubling when acc == point
+            else if (r < 10) { idx = last; neg = !lastneg; } // inverse of the previous point
+            Affine p = (r >= 10 && r < 13) ? ident : pts[idx];
+            Affine ps = neg ? affine_neg(p) : p;
+            xyzz_add_mixed(s, ps);
+            xyzzu_add_affine(u, p, neg);
+            last = idx;
+            lastneg = neg;
+            if ((i & 15) == 0) CHECK(same_point(u, s));
+        }
+        CHECK(same_point(u, s));
+    }
+    // P + P, P - P, from identity, after identity
+    for (int i = 0; i < NP; i++) {
+        XYZZ s = xyzz_identity();
+        XYZZu u = xyzzu_identity();
+        xyzz_add_mixed(s, pts[i]); xyzzu_add_affine(u, pts[i], false);
+        xyzz_add_mixed(s, pts[i]); xyzzu_add_affine(u, pts[i], false);   // doubling
+        CHECK(same_point(u, s));
+        xyzz_add_mixed(s, affine_neg(pts[i])); xyzzu_add_affine(u, pts[i], true);
+        xyzz_add_mixed(s, affine_neg(pts[i])); xyzzu_add_affine(u, pts[i], true);  // -> identity
+        CHECK(xyzz_is_identity(s) && xyzzu_is_identity(u));
+        xyzz_add_mixed(s, pts[(i + 1) % NP]); xyzzu_add_affine(u, pts[(i + 1) % NP], false);
+        CHECK(same_point(u, s));
+    }
+    // full adds: random pairs, equal accumulators (doubling), opposite accumulators, identity operands, running sums
+    for (int it = 0; it < 300; it++) {
+        XYZZ s1 = xyzz_identity(), s2 = xyzz_identity();
+        XYZZu u1 = xyzzu_identity(), u2 = xyzzu_identity();
+        int n1 = (int)(rnd() % 5), n2 = (int)(rnd() % 5);
+        for (int i = 0; i < n1; i++) { int idx = (int)(rnd() % NP); xyzz_add_mixed(s1, pts[idx]); xyzzu_add_affine(u1, pts[idx], false); }
+        int mode = it % 4;
+        if (mode == 0) for (int i = 0; i < n2; i++) { int idx = (int)(rnd() % NP); xyzz_add_mixed(s2, pts[idx]); xyzzu_add_affine(u2, pts[idx], false); }
+        if (mode == 1) { s2 = s1; u2 = u1; }  // a + a
+        if (mode == 2) {                       // a + (-a) built through a different path
+            s2 = s1; u2 = u1;
+            s2.y = fe_neg<Q>(s2.y);
+            u2.y = fu_neg(u2.y);
+        }
+        if (mode == 3) {                       // same point, different representation: (a + b) - b
+            int idx = (int)(rnd() % NP);
+            s2 = s1; u2 = u1;
+            xyzz_add_mixed(s2, pts[idx]); xyzzu_add_affine(u2, pts[idx], false);
+            xyzz_add_mixed(s2, affine_neg(pts[idx])); xyzzu_add_affine(u2, pts[idx], true);
+        }
+        xyzz_add(s1, s2);
+        xyzzu_add(u1, u2);
+        CHECK(same_point(u1, s1));
+        XYZZ d = xyzz_double(s1);
+        XYZZu du = xyzzu_double(u1);
+        CHECK(same_point(du, d));
+        uint32_t k = (uint32_t)(rnd() % 3000);
+        CHECK(same_point(xyzzu_mul_small(u1, k), xyzz_mul_small(s1, k)));
+        // round trip through the E-form
+        CHECK(same_point(xyzzu_from_ext(xyzzu_to_ext(u1)), s1));
+    }
+    // summation by parts, as msm_reduce1 does it
+    {
+        std::vector<XYZZ> bs;
+        std::vector<XYZZu> bu;
+        for (int i = 0; i < 64; i++) {
+            XYZZ s = xyzz_identity();
+            XYZZu u = xyzzu_identity();
+            int n = (int)(rnd() % 4);
+            for (int j = 0; j < n; j++) { int idx = (int)(rnd() % NP); xyzz_add_mixed(s, pts[idx]); xyzzu_add_affine(u, pts[idx], false); }
+            bs.push_back(s);
+            bu.push_back(u);
+        }
+        XYZZ run = xyzz_identity(), acc = xyzz_identity();
+        XYZZu runu = xyzzu_identity(), accu = xyzzu_identity();
+        for (int i = 64; i-- > 0;) {
+            xyzz_add(run, bs[i]); xyzz_add(acc, run);
+            xyzzu_add(runu, bu[i]); xyzzu_add(accu, runu);
+        }
+        CHECK(same_point(accu, acc));
+    }
+    printf("ec fuzz done, failures so far %d\n", failures);
+}
+
+int main() {
+    test_field<FqU>("Fq");
+    test_field<FrU>("Fr");
+    test_ec();
+    printf(failures ? "FIELDU TESTS FAILED (%d)\n" : "fieldu tests ok\n", failures);
+    return failures ? 1 : 0;
+}
