@@ -174,10 +174,20 @@ H2_HD XYZZu xyzzu_from_ext(const XYZZ& p) {
     return o;
 }
 
-// k * p for a small non-negative integer k (double-and-add, vartime)
-H2_HD XYZZu xyzzu_mul_small(const XYZZu& p, uint32_t k) {
+// k * p for a small non-negative integer k < 2^nbits (double-and-add, vartime)
+H2_HD XYZZu xyzzu_mul_small(const XYZZu& p, uint32_t k, uint32_t nbits = 32) {
     XYZZu acc = xyzzu_identity();
-    for (int i = 31; i >= 0; i--) {
+    for (int i = (int)nbits - 1; i >= 0; i--) {
+        acc = xyzzu_double(acc);
+        if ((k >> i) & 1) xyzzu_add(acc, p);
+    }
+    return acc;
+}
+
+// k * p for k < 32 (5-bit double-and-add)
+H2_HD XYZZu xyzzu_mul_small5(const XYZZu& p, uint32_t k) {
+    XYZZu acc = xyzzu_identity();
+    for (int i = 4; i >= 0; i--) {
         acc = xyzzu_double(acc);
         if ((k >> i) & 1) xyzzu_add(acc, p);
     }

@@ -19,8 +19,10 @@
 //                            sums over 2^s buckets, then one workgroup per window
 //   K4  host                 Horner over the W window sums with c doublings each (arithmetic.rs:46-49)
 #include <hipcub/hipcub.hpp>
+#include <string.h>
 
 #include "engine.h"
+#include "host64.h"
 
 namespace h2 {
 
@@ -51,7 +53,8 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const Fe* __restrict__ 
     Fe s = fe_to_canonical<FrP>(scalars[i]);
     uint32_t carry = 0;
     const uint32_t half = 1u << (c - 1);
-    const uint32_t sentinel = W * NB;
+    // key = (window << c) | slot, slot = |digit| - 1 in [0, NB) or NB for a zero digit (skipped): pairs are
+    // written window-major, so each window's n pairs can also be sorted on their own on the low c bits
     for (uint32_t w = 0; w < W; w++) {
         uint32_t d = scalar_bits(s, w * c, c) + carry;
         uint32_t neg = 0;
@@ -62,21 +65,37 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const Fe* __restrict__ 
             carry = 1;
         }
         size_t e = (size_t)w * n + i;
-        keys[e] = d ? (w * NB + d - 1) : sentinel;
+        keys[e] = (w << c) | (d ? d - 1 : NB);
         vals[e] = i | (neg << 31);
     }
 }
 
-// K2a: start[b] = first sorted position with key >= b, for b in [0, W*NB]
-__global__ void msm_bounds_kernel(const uint32_t* __restrict__ keys, uint32_t n_entries, uint32_t n_keys, uint32_t* __restrict__ start) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > n_keys) return;
-    uint32_t lo = 0, hi = n_entries;
+// K2a: per bucket (w, b): start = first sorted position of key (w<<c)|b inside window w's segment, count =
+// number of pairs with that key; also the (clamped) size key and identity permutation for the size sort
+__global__ void msm_bounds_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t c, uint32_t n_buckets,
+                                  uint32_t* __restrict__ start, uint32_t* __restrict__ counts, uint32_t* __restrict__ size_key,
+                                  uint32_t* __restrict__ ids) {
+    uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gb >= n_buckets) return;
+    const uint32_t w = gb >> (c - 1), b = gb & ((1u << (c - 1)) - 1);
+    const uint32_t seg = w * n;
+    const uint32_t k0 = (w << c) | b;
+    uint32_t lo = seg, hi = seg + n;
     while (lo < hi) {
         uint32_t mid = lo + ((hi - lo) >> 1);
-        if (keys[mid] < b) lo = mid + 1; else hi = mid;
+        if (keys[mid] < k0) lo = mid + 1; else hi = mid;
     }
-    start[b] = lo;
+    const uint32_t first = lo;
+    hi = seg + n;
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if (keys[mid] <= k0) lo = mid + 1; else hi = mid;
+    }
+    const uint32_t cnt = lo - first;
+    start[gb] = first;
+    counts[gb] = cnt;
+    size_key[gb] = cnt < 0xffffu ? cnt : 0xffffu;
+    ids[gb] = gb;
 }
 
 struct HeavyBucket {
@@ -94,12 +113,14 @@ __device__ __forceinline__ void accum_signed(XYZZu& acc, const Affine* __restric
 
 // K2: one lane per bucket
 __global__ void __launch_bounds__(256) msm_accum_kernel(const Affine* __restrict__ bases, const uint32_t* __restrict__ vals,
-                                                        const uint32_t* __restrict__ start, uint32_t n_buckets, uint32_t heavy_t,
+                                                        const uint32_t* __restrict__ start, const uint32_t* __restrict__ counts,
+                                                        const uint32_t* __restrict__ perm, uint32_t n_buckets, uint32_t heavy_t,
                                                         uint32_t chunk, XYZZu* __restrict__ buckets, uint32_t* __restrict__ heavy_counts,
                                                         HeavyBucket* __restrict__ heavy_buckets, HeavyChunk* __restrict__ heavy_chunks) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_buckets) return;
-    uint32_t s = start[b], e = start[b + 1];
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_buckets) return;
+    const uint32_t b = perm[t];  // buckets in descending size order
+    uint32_t s = start[b], e = s + counts[b];
     XYZZu acc = xyzzu_identity();
     if (e - s > heavy_t) {
         uint32_t nch = (e - s + chunk - 1) / chunk;
@@ -163,7 +184,16 @@ __global__ void __launch_bounds__(256) msm_heavy_final_kernel(const uint32_t* __
     }
 }
 
-// K3 level 1: lane t of window w folds buckets [t*s1, (t+1)*s1): run = sum B_i, acc = sum (i - t*s1 + 1) B_i
+// K3: summation by parts (arithmetic.rs:95-99), restated so that no lane runs a long chain of dependent
+// EC additions (one XYZZ add is ~3.5 k instructions = ~6 us for a lone wave):
+//   R1  lane t of window w folds s1 = 2^log_s1 consecutive buckets by running sums:
+//         RUN[t] = sum B_i,  ACC[t] = sum (i - t*s1 + 1) B_i         (chain 2*s1)
+//       window sum = sum_t ACC[t] + s1 * sum_t t * RUN[t]
+//   R2  the weighted sum over t is taken digit by digit in radix 32: t = sum_d t_d 32^d, so
+//         sum_t t*RUN[t] = sum_d 32^d sum_v v * T[d][v],   T[d][v] = sum_{t : t_d = v} RUN[t]
+//       one workgroup per (window, d, v) forms T[d][v] (plain sum: per-lane partial + LDS tree); slot d = D
+//       holds 32 partial plain sums of ACC.
+//   R3  one workgroup per window: v*T[d][v] by double-and-add, tree over v, Horner over d, times s1, plus ACC.
 __global__ void __launch_bounds__(256) msm_reduce1_kernel(const XYZZu* __restrict__ buckets, uint32_t n_seg_total, uint32_t log_s1,
                                                           XYZZu* __restrict__ acc_out, XYZZu* __restrict__ run_out) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -179,33 +209,57 @@ __global__ void __launch_bounds__(256) msm_reduce1_kernel(const XYZZu* __restric
     run_out[t] = run;
 }
 
-// K3 level 2: one workgroup per window over its m1 (acc, run) pairs:
-//   window sum = sum_t ACC[t] + s1 * sum_t t * RUN[t]
-__global__ void __launch_bounds__(256) msm_reduce2_kernel(const XYZZu* __restrict__ acc_in, const XYZZu* __restrict__ run_in, uint32_t m1,
-                                                          uint32_t log_s1, XYZZ* __restrict__ window_sums) {
-    __shared__ XYZZu sh[256];
-    const uint32_t w = blockIdx.x;
-    const XYZZu* A = acc_in + (size_t)w * m1;
-    const XYZZu* Rn = run_in + (size_t)w * m1;
-    const uint32_t s2 = (m1 + 255) / 256;
-    const uint32_t lo = threadIdx.x * s2;
-    XYZZu v = xyzzu_identity();
-    if (lo < m1) {
-        uint32_t hi = lo + s2 < m1 ? lo + s2 : m1;
-        XYZZu a = xyzzu_identity(), run2 = xyzzu_identity(), acc2 = xyzzu_identity();
-        for (uint32_t t = hi; t-- > lo;) {
-            xyzzu_add(a, A[t]);
-            xyzzu_add(run2, Rn[t]);
-            if (t != lo) xyzzu_add(acc2, run2);
+struct DigitPlan {
+    uint32_t D;          // number of digits of the segment index t (<= 7)
+    uint32_t width[8];   // bits of digit d (<= 5), split as evenly as possible so every T[d][v] sums equally many terms
+    uint32_t shift[8];   // bit position of digit d
+};
+
+// grid = W * (D + 1) * 32 single-wave workgroups (a 64-lane tree wastes fewer issue slots than a 256-lane
+// one: a wave executes an EC add at full cost however few of its lanes are active); T laid out [w][d][v]
+__global__ void __launch_bounds__(64) msm_reduce2_kernel(const XYZZu* __restrict__ acc_in, const XYZZu* __restrict__ run_in, uint32_t m1,
+                                                         DigitPlan dp, XYZZu* __restrict__ T) {
+    __shared__ XYZZu sh[64];
+    const uint32_t D = dp.D;
+    const uint32_t v = blockIdx.x & 31;
+    const uint32_t d = (blockIdx.x >> 5) % (D + 1);
+    const uint32_t w = (blockIdx.x >> 5) / (D + 1);
+    XYZZu acc = xyzzu_identity();
+    if (d == D) {
+        // plain sum of ACC[t] over t == v (mod 32)
+        const XYZZu* A = acc_in + (size_t)w * m1;
+        for (uint32_t t = v + 32 * threadIdx.x; t < m1; t += 32 * blockDim.x) xyzzu_add(acc, A[t]);
+    } else if (v < (1u << dp.width[d])) {
+        // RUN[t] over the t whose digit d is v: t = hi << (shift + width) | v << shift | lo
+        const XYZZu* Rn = run_in + (size_t)w * m1;
+        const uint32_t sh_d = dp.shift[d], wd = dp.width[d];
+        const uint32_t n_sel = (((m1 - 1) >> (sh_d + wd)) + 1) << sh_d;  // (hi, lo) combinations that can land below m1
+        for (uint32_t q = threadIdx.x; q < n_sel; q += blockDim.x) {
+            uint32_t lo = q & ((1u << sh_d) - 1), hi = q >> sh_d;
+            uint32_t t = (hi << (sh_d + wd)) | (v << sh_d) | lo;
+            if (t < m1) xyzzu_add(acc, Rn[t]);
         }
-        // sum_{t in [lo,hi)} t*RUN[t] = acc2 + lo*run2
-        XYZZu wsum = xyzzu_mul_small(run2, lo);
-        xyzzu_add(wsum, acc2);
-        for (uint32_t k = 0; k < log_s1; k++) wsum = xyzzu_double(wsum);
-        xyzzu_add(wsum, a);
-        v = wsum;
     }
-    XYZZu r = block_tree_sum(v, sh);
+    XYZZu r = block_tree_sum(acc, sh);
+    if (threadIdx.x == 0) T[((size_t)w * (D + 1) + d) * 32 + v] = r;
+}
+
+// one workgroup of 256 per window: lane (d, v) scales T[d][v] by v << shift[d] (double-and-add), one tree over
+// all lanes sums them together with the ACC partial sums, then times s1
+__global__ void __launch_bounds__(256) msm_reduce3_kernel(const XYZZu* __restrict__ T, DigitPlan dp, uint32_t log_s1,
+                                                          XYZZ* __restrict__ window_sums) {
+    __shared__ XYZZu sh[256];
+    const uint32_t D = dp.D;
+    const uint32_t w = blockIdx.x;
+    const XYZZu* Tw = T + (size_t)w * (D + 1) * 32;
+    const uint32_t d = threadIdx.x >> 5, v = threadIdx.x & 31;  // D + 1 <= 8 slots of 32 lanes
+    XYZZu x = xyzzu_identity();
+    if (d < D) {
+        if (v != 0 && v < (1u << dp.width[d])) x = xyzzu_mul_small(Tw[d * 32 + v], (v << dp.shift[d]) << log_s1, dp.shift[d] + dp.width[d] + log_s1);
+    } else if (d == D) {
+        x = Tw[D * 32 + v];
+    }
+    XYZZu r = block_tree_sum(x, sh);
     if (threadIdx.x == 0) window_sums[w] = xyzzu_to_ext(r);  // canonical E-form for the host Horner
 }
 
@@ -232,7 +286,7 @@ static MsmPlan make_plan(size_t n) {
     p.c = c;
     p.W = 254 / c + 1;
     p.NB = 1u << (c - 1);
-    p.log_s1 = (c - 1) < 4 ? (c - 1) : 4;
+    p.log_s1 = (c - 1) < 3 ? (c - 1) : 3;  // short chains when there are few buckets, 8-bucket segments when many
     size_t avg = (n * p.W) / ((size_t)p.W * p.NB) + 1;
     size_t t = 4 * avg;
     if (t < 2048) t = 2048;
@@ -245,12 +299,12 @@ uint32_t msm_get_window(size_t n) { return make_plan(n).c; }
 
 // host Horner over window sums (arithmetic.rs:46-49): acc = sum_w 2^(c*w) * S_w
 static XYZZ combine_windows(const XYZZ* ws, const MsmPlan& p) {
-    XYZZ acc = xyzz_identity();
+    h64::P acc = h64::identity();
     for (uint32_t w = p.W; w-- > 0;) {
-        for (uint32_t k = 0; k < p.c; k++) acc = xyzz_double(acc);
-        xyzz_add(acc, ws[w]);
+        for (uint32_t k = 0; k < p.c; k++) acc = h64::pdouble(acc);
+        h64::padd(acc, h64::from_xyzz(ws[w]));
     }
-    return acc;
+    return h64::to_xyzz(acc);
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -267,20 +321,45 @@ static int msm_device_chunk(Ctx* c, const Fe* d_scalars, const Affine* d_bases, 
     const size_t max_chunks = E / p.chunk + E / p.heavy_t + 16;  // sum of ceil(cnt/chunk) over buckets with cnt > heavy_t
     const size_t max_heavy = E / p.heavy_t + 16;
 
+    // Small inputs: one radix sort over (window, slot); large inputs: one sort per window on the slot bits
+    // only (the pairs are already window-major) -- 2 passes of 8 bits instead of 3 over all n*W pairs.
+    const bool per_window_sort = n >= ((size_t)1 << 22);
     size_t cub_bytes = 0;
-    uint32_t end_bit = 1;
-    while ((1ull << end_bit) <= (uint64_t)n_buckets) end_bit++;
+    uint32_t wbits = 0;
+    while ((1u << wbits) < p.W) wbits++;
+    const int end_bit = per_window_sort ? (int)p.c : (int)(p.c + wbits);
     H2_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                                (uint32_t*)nullptr, (int)E, 0, (int)end_bit, s));
+                                                (uint32_t*)nullptr, (int)(per_window_sort ? n : E), 0, end_bit, s));
     // carve the workspace
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     size_t o_keys0 = carve(E * 4), o_keys1 = carve(E * 4), o_vals0 = carve(E * 4), o_vals1 = carve(E * 4);
     size_t o_cub = carve(cub_bytes);
     size_t o_start = carve(((size_t)n_buckets + 2) * 4);
+    size_t o_counts = carve((size_t)n_buckets * 4);
+    size_t cub2_bytes = 0;
+    H2_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, cub2_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                                          (uint32_t*)nullptr, (int)n_buckets, 0, 16, s));
+    size_t o_cnt0 = carve((size_t)n_buckets * 4), o_cnt1 = carve((size_t)n_buckets * 4);
+    size_t o_id0 = carve((size_t)n_buckets * 4), o_id1 = carve((size_t)n_buckets * 4);
+    size_t o_cub2 = carve(cub2_bytes);
     size_t o_buckets = carve((size_t)n_buckets * sizeof(XYZZu));
     size_t o_acc = carve((size_t)p.W * m1 * sizeof(XYZZu)), o_run = carve((size_t)p.W * m1 * sizeof(XYZZu));
     size_t o_wsum = carve((size_t)p.W * sizeof(XYZZ));
+    // digits of the segment index t < m1: ceil(bits / 5) digits of near-equal width
+    uint32_t tbits = 0;
+    while ((1u << tbits) < m1) tbits++;
+    DigitPlan dplan;
+    memset(&dplan, 0, sizeof(dplan));
+    uint32_t D = tbits ? (tbits + 4) / 5 : 1;
+    dplan.D = D;
+    for (uint32_t d = 0, pos = 0; d < D; d++) {
+        uint32_t wd = tbits / D + (d < tbits % D ? 1 : 0);
+        dplan.width[d] = wd;
+        dplan.shift[d] = pos;
+        pos += wd;
+    }
+    size_t o_T = carve((size_t)p.W * (D + 1) * 32 * sizeof(XYZZu));
     size_t o_hcnt = carve(16);
     size_t o_hb = carve(max_heavy * sizeof(HeavyBucket)), o_hc = carve(max_chunks * sizeof(HeavyChunk));
     size_t o_hs = carve(max_chunks * sizeof(XYZZu));
@@ -290,9 +369,13 @@ static int msm_device_chunk(Ctx* c, const Fe* d_scalars, const Affine* d_bases, 
     uint32_t *keys0 = (uint32_t*)(base + o_keys0), *keys1 = (uint32_t*)(base + o_keys1);
     uint32_t *vals0 = (uint32_t*)(base + o_vals0), *vals1 = (uint32_t*)(base + o_vals1);
     uint32_t* start = (uint32_t*)(base + o_start);
+    uint32_t* counts = (uint32_t*)(base + o_counts);
+    uint32_t *cnt0 = (uint32_t*)(base + o_cnt0), *cnt1 = (uint32_t*)(base + o_cnt1);
+    uint32_t *id0 = (uint32_t*)(base + o_id0), *id1 = (uint32_t*)(base + o_id1);
     XYZZu* buckets = (XYZZu*)(base + o_buckets);
     XYZZu *accs = (XYZZu*)(base + o_acc), *runs = (XYZZu*)(base + o_run);
     XYZZ* wsum = (XYZZ*)(base + o_wsum);
+    XYZZu* Tsum = (XYZZu*)(base + o_T);
     uint32_t* hcnt = (uint32_t*)(base + o_hcnt);
     HeavyBucket* hb = (HeavyBucket*)(base + o_hb);
     HeavyChunk* hc = (HeavyChunk*)(base + o_hc);
@@ -308,13 +391,20 @@ static int msm_device_chunk(Ctx* c, const Fe* d_scalars, const Affine* d_bases, 
     c->timer_end(t0, s);
 
     int t1 = c->timer_begin("msm_sort", s);
-    H2_CHECK(hipcub::DeviceRadixSort::SortPairs(base + o_cub, cub_bytes, keys0, keys1, vals0, vals1, (int)E, 0, (int)end_bit, s));
-    hipLaunchKernelGGL(msm_bounds_kernel, dim3((n_buckets + 1 + 255) / 256), dim3(256), 0, s, keys1, (uint32_t)E, n_buckets, start);
+    if (per_window_sort) {
+        for (uint32_t w = 0; w < p.W; w++)
+            H2_CHECK(hipcub::DeviceRadixSort::SortPairs(base + o_cub, cub_bytes, keys0 + (size_t)w * n, keys1 + (size_t)w * n, vals0 + (size_t)w * n,
+                                                        vals1 + (size_t)w * n, (int)n, 0, end_bit, s));
+    } else {
+        H2_CHECK(hipcub::DeviceRadixSort::SortPairs(base + o_cub, cub_bytes, keys0, keys1, vals0, vals1, (int)E, 0, end_bit, s));
+    }
+    hipLaunchKernelGGL(msm_bounds_kernel, dim3((n_buckets + 255) / 256), dim3(256), 0, s, keys1, (uint32_t)n, p.c, n_buckets, start, counts, cnt0, id0);
     H2_CHECK(hipGetLastError());
+    H2_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(base + o_cub2, cub2_bytes, cnt0, cnt1, id0, id1, (int)n_buckets, 0, 16, s));
     c->timer_end(t1, s);
 
     int t2 = c->timer_begin("msm_accum", s);
-    hipLaunchKernelGGL(msm_accum_kernel, dim3((n_buckets + 255) / 256), dim3(256), 0, s, d_bases, vals1, start, n_buckets, p.heavy_t, p.chunk,
+    hipLaunchKernelGGL(msm_accum_kernel, dim3((n_buckets + 255) / 256), dim3(256), 0, s, d_bases, vals1, start, counts, id1, n_buckets, p.heavy_t, p.chunk,
                        buckets, hcnt, hb, hc);
     H2_CHECK(hipGetLastError());
     c->timer_end(t2, s);
@@ -332,7 +422,9 @@ static int msm_device_chunk(Ctx* c, const Fe* d_scalars, const Affine* d_bases, 
     uint32_t n_seg = p.W * m1;
     hipLaunchKernelGGL(msm_reduce1_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, s, buckets, n_seg, p.log_s1, accs, runs);
     H2_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(msm_reduce2_kernel, dim3(p.W), dim3(256), 0, s, accs, runs, m1, p.log_s1, wsum);
+    hipLaunchKernelGGL(msm_reduce2_kernel, dim3(p.W * (D + 1) * 32), dim3(64), 0, s, accs, runs, m1, dplan, Tsum);
+    H2_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(msm_reduce3_kernel, dim3(p.W), dim3(256), 0, s, Tsum, dplan, p.log_s1, wsum);
     H2_CHECK(hipGetLastError());
     c->timer_end(t4, s);
     c->timer_end(t_all, s);

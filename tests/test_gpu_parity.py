@@ -246,3 +246,106 @@ def test_cpp_host_mirror(h2):
     r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "host mirror tests ok" in r.stdout
+
+
+def test_reentrancy_from_threads(h2, oracle):
+    """keygen_pk re-enters best_fft from several rayon workers at once
+    (plonk/permutation/keygen.rs:216-233): concurrent callers must each get the right answer."""
+    import threading
+    k = 12
+    d, _ = oracle.domain_new(2, k)
+    inputs = [oracle.gen_scalars(100 + t, 1 << k) for t in range(6)]
+    bases = oracle.gen_points(55, 1 << k, num_threads=NT)
+    want_fft = [oracle.best_fft(a, d.fe("omega"), k, 2) for a in inputs]
+    want_msm = [oracle.g1_to_affine(oracle.best_multiexp(a, bases, 4)) for a in inputs]
+    errs = []
+
+    def worker(t):
+        try:
+            for _ in range(3):
+                a = inputs[t].copy()
+                h2.best_fft(a, d.fe("omega"), k)
+                if not np.array_equal(a, want_fft[t]):
+                    errs.append(("fft", t))
+                got = aff(h2, h2.best_multiexp(inputs[t], bases))
+                if not np.array_equal(got, want_msm[t]):
+                    errs.append(("msm", t))
+        except Exception as e:  # noqa: BLE001
+            errs.append((repr(e), t))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errs, errs
+
+
+def test_create_proof_call_trace_k17(h2, oracle):
+    """BASELINE.json configs[4] as a call-trace replay (the Rust create_proof itself
+    cannot run here): the MSM / NTT calls one KZG proof of examples/circuit-layout.rs's MyCircuit makes at
+    k = 17 -- 16 commits of 2^17, 10 lagrange_to_coeff of 2^17, 10 coeff_to_extended 2^17 -> 2^19,
+    1 extended_to_coeff of 2^19 -- on prover-like and dense columns, every call checked against the oracle."""
+    k = 17
+    n = 1 << k
+    d, _ = oracle.domain_new(4, k)
+    assert d.extended_k == 19
+    dom = _domain(h2, d)
+    g = oracle.gen_points(0xABCD, n, num_threads=NT)          # stands for params.g
+    g_lagrange = oracle.gen_points(0xABCE, n, num_threads=NT)  # stands for params.g_lagrange
+    params = h2.ParamsKZG(k, g, g_lagrange)
+    try:
+        sparse = [_prover_like(oracle, n, 500 + i) for i in range(5)]               # advice columns (plonk/prover.rs:361-365)
+        dense = [oracle.gen_scalars(600 + i, n, num_threads=NT) for i in range(5)]  # lookup / permutation products
+        lag_cols = sparse + dense
+        # commit_lagrange x10 (advice, lookup permuted, permutation z, lookup z), commit x6 (random poly, h pieces, shplonk)
+        for col in lag_cols:
+            want = oracle.g1_to_affine(oracle.best_multiexp(col, g_lagrange, NT))
+            assert np.array_equal(aff(h2, params.commit_lagrange(col)), want)
+        coeff_cols = []
+        for col in lag_cols:                                                        # lagrange_to_coeff x10
+            c = dom.lagrange_to_coeff(col)
+            assert np.array_equal(c, oracle.lagrange_to_coeff(d, col, NT))
+            coeff_cols.append(c)
+        for c in coeff_cols[:6]:                                                    # commit x6
+            want = oracle.g1_to_affine(oracle.best_multiexp(c, g, NT))
+            assert np.array_equal(aff(h2, params.commit(c)), want)
+        ext = None
+        for c in coeff_cols:                                                        # coeff_to_extended x10
+            ext = dom.coeff_to_extended(c)
+            assert np.array_equal(ext, oracle.coeff_to_extended(d, c, NT))
+        h = dom.extended_to_coeff(ext)                                              # extended_to_coeff x1
+        assert np.array_equal(h, oracle.extended_to_coeff(d, ext, NT))
+    finally:
+        params.close()
+
+
+def test_msm_2p24_shard_fold_property(h2, oracle):
+    """BASELINE.json configs[3] shape on one GPU: 2^24 pairs; the full MSM equals the fold of 8 shard MSMs
+    (the multi-GPU partition), and one shard equals the oracle."""
+    n = 1 << 24
+    ds = h2.gen_scalars_device(0x5EED0001, n)
+    dp = h2.gen_points_device(0x5EED0002, n)
+    full = aff(h2, h2.msm_device(ds, dp))
+    per = n // 8
+    parts = [h2.msm_device(ds[i * per:(i + 1) * per], dp[i * per:(i + 1) * per]) for i in range(8)]
+    assert np.array_equal(aff(h2, h2.g1_fold(np.stack(parts))), full)
+    sc, bs = h2.to_numpy_u64(ds[:per]), h2.to_numpy_u64(dp[:per])
+    assert np.array_equal(aff(h2, parts[0]), oracle.g1_to_affine(oracle.best_multiexp(sc, bs, NT)))
+
+
+@pytest.mark.parametrize("k", [24, 26])
+def test_ntt_large_roundtrip(h2, oracle, k):
+    """metric range 2^20..2^26: NTT then iNTT returns the input (2 GiB at k = 26); linearity spot check"""
+    import torch
+    d, _ = oracle.domain_new(2, k)
+    da = h2.gen_scalars_device(0x5EED0003, 1 << k)
+    keep = da[:4096].clone()
+    ref = da.clone()
+    h2.ntt_device(da, d.fe("omega"), k)
+    # X[0] = sum of inputs: check against a device-side independent reduction is not available; use DC term
+    # via the inverse instead: round trip must restore every limb
+    h2.ifft_device(da, d.fe("omega_inv"), k, d.fe("ifft_divisor"))
+    torch.cuda.synchronize()
+    assert torch.equal(da, ref)
+    assert torch.equal(da[:4096], keep)
