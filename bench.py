@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20, help="pairs per GPU = 2^log_n")
     ap.add_argument("--ntt-log-n", type=int, default=22)
     ap.add_argument("--window", type=int, default=0, help="MSM window bits (0 = engine default)")
+    ap.add_argument("--groups", type=int, default=0, help="MSM window groups pipelined over streams (0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     args = ap.parse_args()
@@ -80,6 +81,8 @@ def main():
     h2.init(local_rank)
     if args.window:
         h2.set_msm_window(args.window)
+    if args.groups:
+        h2.set_msm_groups(args.groups)
 
     n = 1 << args.log_n
     c = h2.get_msm_window(n)

@@ -289,6 +289,10 @@ def set_msm_window(c):
     _check(lib().h2hip_set_msm_window(ctypes.c_uint32(c)), "h2hip_set_msm_window")
 
 
+def set_msm_groups(g):
+    _check(lib().h2hip_set_msm_groups(ctypes.c_uint32(g)), "h2hip_set_msm_groups")
+
+
 def get_msm_window(n):
     return int(lib().h2hip_get_msm_window(n))
 

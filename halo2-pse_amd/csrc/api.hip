@@ -11,6 +11,7 @@ namespace h2 {
 int gen_scalars_device(uint64_t seed, uint64_t start, size_t n, Fe* d_out, hipStream_t s);
 int gen_points_device(uint64_t seed, uint64_t start, size_t n, Affine* d_out, hipStream_t s);
 void msm_set_window(uint32_t c);
+void msm_set_groups(uint32_t g);
 uint32_t msm_get_window(size_t n);
 
 static thread_local char g_err[512] = "";
@@ -110,6 +111,17 @@ int Ctx::ws_release(hipStream_t s) {
     H2_CHECK(hipEventRecord(ws_event, s));
     ws_last_stream = s;
     ws_used = true;
+    return 0;
+}
+
+int Ctx::ensure_aux(size_t n_events) {
+    if (!aux1) H2_CHECK(hipStreamCreateWithFlags(&aux1, hipStreamNonBlocking));
+    if (!aux2) H2_CHECK(hipStreamCreateWithFlags(&aux2, hipStreamNonBlocking));
+    while (aux_events.size() < n_events) {
+        hipEvent_t e;
+        H2_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        aux_events.push_back(e);
+    }
     return 0;
 }
 
@@ -254,6 +266,11 @@ void h2hip_shutdown(void) {
     c->misc.release();
     (void)hipStreamDestroy(c->stream);
     c->stream = nullptr;
+    for (auto e : c->aux_events) (void)hipEventDestroy(e);
+    c->aux_events.clear();
+    if (c->aux1) (void)hipStreamDestroy(c->aux1);
+    if (c->aux2) (void)hipStreamDestroy(c->aux2);
+    c->aux1 = c->aux2 = nullptr;
     if (c->ws_event) (void)hipEventDestroy(c->ws_event);
     c->ws_event = nullptr;
     c->ws_used = false;
@@ -525,6 +542,15 @@ int h2hip_set_msm_window(uint32_t c) {
 }
 
 uint32_t h2hip_get_msm_window(size_t n) { return msm_get_window(n); }
+
+int h2hip_set_msm_groups(uint32_t g) {
+    if (g > 16) {
+        set_error("msm groups must be 0 (auto) or 1..16");
+        return H2HIP_EINVAL;
+    }
+    msm_set_groups(g);
+    return 0;
+}
 
 int h2hip_profile_enable(int on) {
     Ctx* c = ctx();

@@ -98,9 +98,9 @@ H2_HD void xyzzu_add_mixed(XYZZu& acc, const Fu& px, const Fu& py) {
     Fu pp = fu_sqr<QU>(p_);
     Fu ppp = fu_mul<QU>(p_, pp);
     Fu q = fu_mul<QU>(acc.x, pp);
-    Fu x3 = fu_norm(fu_sub(fu_sub(fu_sqr<QU>(r), ppp), fu_dbl(q)));
+    Fu x3 = fu_sqr_sub<QU>(r, fu_add(ppp, fu_dbl(q)));    // R^2 - PPP - 2Q, one reduction, already normalised
     Fu t = fu_sub(q, x3);
-    Fu y3 = fu_norm(fu_sub(fu_mul<QU>(r, t), fu_mul<QU>(acc.y, ppp)));
+    Fu y3 = fu_mul_sub<QU>(r, t, acc.y, ppp);             // R*(Q - X3) - Y1*PPP, one reduction
     acc.x = x3;
     acc.y = y3;
     acc.zz = fu_mul<QU>(acc.zz, pp);
@@ -133,9 +133,9 @@ H2_HD void xyzzu_add(XYZZu& a, const XYZZu& b) {
     Fu pp = fu_sqr<QU>(p_);
     Fu ppp = fu_mul<QU>(p_, pp);
     Fu q = fu_mul<QU>(u1, pp);
-    Fu x3 = fu_norm(fu_sub(fu_sub(fu_sqr<QU>(r), ppp), fu_dbl(q)));
+    Fu x3 = fu_sqr_sub<QU>(r, fu_add(ppp, fu_dbl(q)));
     Fu t = fu_sub(q, x3);
-    Fu y3 = fu_norm(fu_sub(fu_mul<QU>(r, t), fu_mul<QU>(s1, ppp)));
+    Fu y3 = fu_mul_sub<QU>(r, t, s1, ppp);
     a.x = x3;
     a.y = y3;
     a.zz = fu_mul<QU>(fu_mul<QU>(a.zz, b.zz), pp);

@@ -85,6 +85,10 @@ struct Ctx {
     bool ws_used = false;
     int ws_acquire(hipStream_t s);
     int ws_release(hipStream_t s);
+    // internal streams + events for the MSM's window-group pipeline
+    hipStream_t aux1 = nullptr, aux2 = nullptr;
+    std::vector<hipEvent_t> aux_events;
+    int ensure_aux(size_t n_events);
 };
 
 Ctx* ctx();             // the process-wide context (one process per GPU)

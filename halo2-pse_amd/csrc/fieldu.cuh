@@ -214,9 +214,93 @@ H2_HD Fu fu_mul(const Fu& a, const Fu& b) {
     return r;
 }
 
+// General fused form: (a*b [- c*d] [- h * 2^261]) / 2^261 (mod p) with ONE Montgomery reduction.
+//   SQR : b is ignored, a*a uses the symmetric 45 products
+//   TWO : subtract the second product c*d in the same columns (bound: 18 * La*Lb ... see below)
+//   HI  : subtract h from the high half (h * 2^261 is h shifted up by 9 limbs), i.e. result = a*b/2^261 - h
+// Column bound: (9 or 18) * max|l|^2 + 9 * 2^58 + |h| < 2^63: with |l| < 2^29 everywhere the two-product form
+// peaks at 27 * 2^58 = 2^62.75.  The result always has limbs 0..7 in [0, 2^29) (no fu_norm needed after it).
+template <class U, bool SQR, bool TWO, bool HI>
+H2_HD Fu fu_fused(const Fu& a, const Fu& b, const Fu& c, const Fu& d, const Fu& h) {
+#ifdef H2_FU_CHECK
+    {
+        int64_t ma = 0, mb = 0, mc = 0, md = 0;
+        for (int i = 0; i < 9; i++) {
+            int64_t x;
+            x = a.l[i] < 0 ? -(int64_t)a.l[i] : a.l[i]; if (x > ma) ma = x;
+            x = b.l[i] < 0 ? -(int64_t)b.l[i] : b.l[i]; if (x > mb) mb = x;
+            x = c.l[i] < 0 ? -(int64_t)c.l[i] : c.l[i]; if (x > mc) mc = x;
+            x = d.l[i] < 0 ? -(int64_t)d.l[i] : d.l[i]; if (x > md) md = x;
+        }
+        if (SQR) mb = ma;
+        __int128 bound = (__int128)9 * ma * mb + (TWO ? (__int128)9 * mc * md : 0) + ((__int128)9 << 58) + ((__int128)1 << 36);
+        assert(bound < ((__int128)1 << 63));
+    }
+#endif
+    int64_t acc = 0;
+    uint32_t m[9];
+    int32_t a2[9], nc[9];
+    Fu r;
+    if (SQR) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) a2[i] = a.l[i] * 2;
+    }
+    if (TWO) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) nc[i] = -c.l[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        const int lo = k > 8 ? k - 8 : 0, hi = k < 8 ? k : 8;
+        if (SQR) {
+#pragma unroll
+            for (int i = lo; i <= hi; i++) {
+                int j = k - i;
+                if (i < j) acc += (int64_t)a2[i] * (int64_t)a.l[j];
+                else if (i == j) acc += (int64_t)a.l[i] * (int64_t)a.l[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = lo; i <= hi; i++) acc += (int64_t)a.l[i] * (int64_t)b.l[k - i];
+        }
+        if (TWO) {
+#pragma unroll
+            for (int i = lo; i <= hi; i++) acc += (int64_t)nc[i] * (int64_t)d.l[k - i];
+        }
+        if (k < 9) {
+#pragma unroll
+            for (int i = 0; i < k; i++) acc += (int64_t)m[i] * (int64_t)U::P[k - i];
+            m[k] = ((uint32_t)acc * U::INV) & H2_MASK29;
+            acc += (int64_t)m[k] * (int64_t)U::P[0];
+            acc >>= 29;  // exact
+        } else {
+#pragma unroll
+            for (int i = k - 8; i <= 8; i++) acc += (int64_t)m[i] * (int64_t)U::P[k - i];
+            if (HI) acc -= (int64_t)h.l[k - 9];
+            r.l[k - 9] = (int32_t)((uint32_t)acc & H2_MASK29);
+            acc >>= 29;
+        }
+    }
+    if (HI) acc -= (int64_t)h.l[8];
+    r.l[8] = (int32_t)acc;
+    return r;
+}
+
 template <class U>
 H2_HD Fu fu_sqr(const Fu& a) {
-    return fu_mul<U>(a, a);
+    return fu_fused<U, true, false, false>(a, a, a, a, a);
+}
+
+// (a*b - c*d) / 2^261
+template <class U>
+H2_HD Fu fu_mul_sub(const Fu& a, const Fu& b, const Fu& c, const Fu& d) {
+    return fu_fused<U, false, true, false>(a, b, c, d, a);
+}
+
+// a*a / 2^261 - h   (h loose, |h.l| < 2^31)
+template <class U>
+H2_HD Fu fu_sqr_sub(const Fu& a, const Fu& h) {
+    return fu_fused<U, true, false, true>(a, a, a, a, h);
 }
 
 // Cheap necessary condition for value == k*p with |k| <= 8 (so for value == 0 mod p when

@@ -72,11 +72,12 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const Fe* __restrict__ 
 
 // K2a: per bucket (w, b): start = first sorted position of key (w<<c)|b inside window w's segment, count =
 // number of pairs with that key; also the (clamped) size key and identity permutation for the size sort
-__global__ void msm_bounds_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t c, uint32_t n_buckets,
+__global__ void msm_bounds_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t c, uint32_t gb_base, uint32_t n_buckets,
                                   uint32_t* __restrict__ start, uint32_t* __restrict__ counts, uint32_t* __restrict__ size_key,
                                   uint32_t* __restrict__ ids) {
     uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x;
     if (gb >= n_buckets) return;
+    gb += gb_base;
     const uint32_t w = gb >> (c - 1), b = gb & ((1u << (c - 1)) - 1);
     const uint32_t seg = w * n;
     const uint32_t k0 = (w << c) | b;
@@ -264,7 +265,9 @@ __global__ void __launch_bounds__(256) msm_reduce3_kernel(const XYZZu* __restric
 }
 
 static uint32_t g_window_override = 0;
+static uint32_t g_groups_override = 0;
 void msm_set_window(uint32_t c) { g_window_override = c; }
+void msm_set_groups(uint32_t g) { g_groups_override = g; }
 
 static MsmPlan make_plan(size_t n) {
     MsmPlan p;
@@ -309,6 +312,12 @@ static XYZZ combine_windows(const XYZZ* ws, const MsmPlan& p) {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// One MSM of n <= 2^26 pairs.  The W windows are processed in G groups pipelined over three streams so
+// that the memory-bound sort of group g+1 and the latency-bound reduction of group g-1 run under the
+// VALU-bound accumulation of group g:
+//   aux1:  sort(0) bounds(0) | sort(1) bounds(1) | ...
+//   s   :  digits | accum(0) heavy(0) | accum(1) heavy(1) | ...                 | copy-out
+//   aux2:                    | reduce(0)           | reduce(1) ...  | reduce(G-1)
 static int msm_device_chunk(Ctx* c, const Fe* d_scalars, const Affine* d_bases, size_t n, XYZZ* h_out, hipStream_t s) {
     MsmPlan p = make_plan(n);
     const size_t E = n * p.W;
@@ -316,20 +325,28 @@ static int msm_device_chunk(Ctx* c, const Fe* d_scalars, const Affine* d_bases, 
         set_error("msm: n*W = %zu pairs exceeds the 2^31 sort limit (window override too small?)", E);
         return 1;
     }
+    if (p.W > MSM_MAX_WINDOWS * 2) {
+        set_error("msm: too many windows");
+        return 1;
+    }
     const uint32_t n_buckets = p.W * p.NB;
     const uint32_t m1 = p.NB >> p.log_s1;
-    const size_t max_chunks = E / p.chunk + E / p.heavy_t + 16;  // sum of ceil(cnt/chunk) over buckets with cnt > heavy_t
-    const size_t max_heavy = E / p.heavy_t + 16;
+    const uint32_t G = (g_groups_override ? g_groups_override : 1u);
+    const uint32_t wpg = (p.W + G - 1) / G;  // windows per group
 
-    // Small inputs: one radix sort over (window, slot); large inputs: one sort per window on the slot bits
-    // only (the pairs are already window-major) -- 2 passes of 8 bits instead of 3 over all n*W pairs.
+    // Small inputs: one radix sort per group over (window, slot); large inputs: one sort per window on the slot
+    // bits only (the pairs are already window-major) -- 2 passes of 8 bits instead of 3.
     const bool per_window_sort = n >= ((size_t)1 << 22);
     size_t cub_bytes = 0;
     uint32_t wbits = 0;
     while ((1u << wbits) < p.W) wbits++;
     const int end_bit = per_window_sort ? (int)p.c : (int)(p.c + wbits);
+    const size_t Eg_max = (size_t)wpg * n;
     H2_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                                (uint32_t*)nullptr, (int)(per_window_sort ? n : E), 0, end_bit, s));
+                                                (uint32_t*)nullptr, (int)(per_window_sort ? n : Eg_max), 0, end_bit, s));
+    const uint32_t nbg_max = wpg * p.NB;
+    const size_t max_chunks = Eg_max / p.chunk + Eg_max / p.heavy_t + 16;  // per group: sum of ceil(cnt/chunk) over buckets with cnt > heavy_t
+    const size_t max_heavy = Eg_max / p.heavy_t + 16;
     // carve the workspace
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -339,7 +356,7 @@ static int msm_device_chunk(Ctx* c, const Fe* d_scalars, const Affine* d_bases, 
     size_t o_counts = carve((size_t)n_buckets * 4);
     size_t cub2_bytes = 0;
     H2_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, cub2_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                                          (uint32_t*)nullptr, (int)n_buckets, 0, 16, s));
+                                                          (uint32_t*)nullptr, (int)nbg_max, 0, 16, s));
     size_t o_cnt0 = carve((size_t)n_buckets * 4), o_cnt1 = carve((size_t)n_buckets * 4);
     size_t o_id0 = carve((size_t)n_buckets * 4), o_id1 = carve((size_t)n_buckets * 4);
     size_t o_cub2 = carve(cub2_bytes);
@@ -360,10 +377,12 @@ static int msm_device_chunk(Ctx* c, const Fe* d_scalars, const Affine* d_bases, 
         pos += wd;
     }
     size_t o_T = carve((size_t)p.W * (D + 1) * 32 * sizeof(XYZZu));
-    size_t o_hcnt = carve(16);
-    size_t o_hb = carve(max_heavy * sizeof(HeavyBucket)), o_hc = carve(max_chunks * sizeof(HeavyChunk));
-    size_t o_hs = carve(max_chunks * sizeof(XYZZu));
+    size_t o_hcnt = carve(16 * G);
+    size_t o_hb = carve(G * max_heavy * sizeof(HeavyBucket)), o_hc = carve(G * max_chunks * sizeof(HeavyChunk));
+    size_t o_hs = carve(G * max_chunks * sizeof(XYZZu));
     int rc = c->msm_ws.ensure(off);
+    if (rc) return rc;
+    rc = c->ensure_aux(3 * G + 2);
     if (rc) return rc;
     char* base = (char*)c->msm_ws.p;
     uint32_t *keys0 = (uint32_t*)(base + o_keys0), *keys1 = (uint32_t*)(base + o_keys1);
@@ -380,60 +399,85 @@ static int msm_device_chunk(Ctx* c, const Fe* d_scalars, const Affine* d_bases, 
     HeavyBucket* hb = (HeavyBucket*)(base + o_hb);
     HeavyChunk* hc = (HeavyChunk*)(base + o_hc);
     XYZZu* hs = (XYZZu*)(base + o_hs);
+    hipStream_t a1 = G > 1 ? c->aux1 : s, a2 = G > 1 ? c->aux2 : s;
+    hipEvent_t* ev = c->aux_events.data();
 
     rc = c->ws_acquire(s);
     if (rc) return rc;
     int t_all = c->timer_begin("msm_total", s);
     int t0 = c->timer_begin("msm_digits", s);
-    H2_CHECK(hipMemsetAsync(hcnt, 0, 16, s));
+    H2_CHECK(hipMemsetAsync(hcnt, 0, 16 * G, s));
     hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, d_scalars, (uint32_t)n, p.c, p.W, p.NB, keys0, vals0);
     H2_CHECK(hipGetLastError());
     c->timer_end(t0, s);
-
-    int t1 = c->timer_begin("msm_sort", s);
-    if (per_window_sort) {
-        for (uint32_t w = 0; w < p.W; w++)
-            H2_CHECK(hipcub::DeviceRadixSort::SortPairs(base + o_cub, cub_bytes, keys0 + (size_t)w * n, keys1 + (size_t)w * n, vals0 + (size_t)w * n,
-                                                        vals1 + (size_t)w * n, (int)n, 0, end_bit, s));
-    } else {
-        H2_CHECK(hipcub::DeviceRadixSort::SortPairs(base + o_cub, cub_bytes, keys0, keys1, vals0, vals1, (int)E, 0, end_bit, s));
+    if (G > 1) {
+        H2_CHECK(hipEventRecord(ev[0], s));
+        H2_CHECK(hipStreamWaitEvent(a1, ev[0], 0));
     }
-    hipLaunchKernelGGL(msm_bounds_kernel, dim3((n_buckets + 255) / 256), dim3(256), 0, s, keys1, (uint32_t)n, p.c, n_buckets, start, counts, cnt0, id0);
-    H2_CHECK(hipGetLastError());
-    H2_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(base + o_cub2, cub2_bytes, cnt0, cnt1, id0, id1, (int)n_buckets, 0, 16, s));
-    c->timer_end(t1, s);
 
-    int t2 = c->timer_begin("msm_accum", s);
-    hipLaunchKernelGGL(msm_accum_kernel, dim3((n_buckets + 255) / 256), dim3(256), 0, s, d_bases, vals1, start, counts, id1, n_buckets, p.heavy_t, p.chunk,
-                       buckets, hcnt, hb, hc);
-    H2_CHECK(hipGetLastError());
-    c->timer_end(t2, s);
+    for (uint32_t g = 0; g < G; g++) {
+        const uint32_t w0 = g * wpg, w1 = (w0 + wpg < p.W) ? w0 + wpg : p.W;
+        if (w0 >= w1) break;
+        const uint32_t Wg = w1 - w0, gb0 = w0 * p.NB, nbg = Wg * p.NB;
+        const size_t e0 = (size_t)w0 * n, Eg = (size_t)Wg * n;
 
-    int t3 = c->timer_begin("msm_heavy", s);
-    uint32_t hgrid = (uint32_t)(max_chunks < (size_t)c->sm_count * 4 ? max_chunks : (size_t)c->sm_count * 4);
-    hipLaunchKernelGGL(msm_heavy_chunk_kernel, dim3(hgrid), dim3(256), 0, s, d_bases, vals1, hcnt, hc, hs);
-    H2_CHECK(hipGetLastError());
-    uint32_t fgrid = (uint32_t)(max_heavy < (size_t)c->sm_count ? max_heavy : (size_t)c->sm_count);
-    hipLaunchKernelGGL(msm_heavy_final_kernel, dim3(fgrid), dim3(256), 0, s, hcnt, hb, hs, buckets);
-    H2_CHECK(hipGetLastError());
-    c->timer_end(t3, s);
+        // ---- aux1: sort + bucket bounds + size order of this group
+        int t1 = c->timer_begin("msm_sort", a1);
+        if (per_window_sort) {
+            for (uint32_t w = w0; w < w1; w++)
+                H2_CHECK(hipcub::DeviceRadixSort::SortPairs(base + o_cub, cub_bytes, keys0 + (size_t)w * n, keys1 + (size_t)w * n,
+                                                            vals0 + (size_t)w * n, vals1 + (size_t)w * n, (int)n, 0, end_bit, a1));
+        } else {
+            H2_CHECK(hipcub::DeviceRadixSort::SortPairs(base + o_cub, cub_bytes, keys0 + e0, keys1 + e0, vals0 + e0, vals1 + e0, (int)Eg, 0, end_bit, a1));
+        }
+        hipLaunchKernelGGL(msm_bounds_kernel, dim3((nbg + 255) / 256), dim3(256), 0, a1, keys1, (uint32_t)n, p.c, gb0, nbg, start, counts, cnt0, id0);
+        H2_CHECK(hipGetLastError());
+        H2_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(base + o_cub2, cub2_bytes, cnt0 + gb0, cnt1 + gb0, id0 + gb0, id1 + gb0, (int)nbg, 0, 16, a1));
+        c->timer_end(t1, a1);
+        if (G > 1) {
+            H2_CHECK(hipEventRecord(ev[1 + g], a1));
+            H2_CHECK(hipStreamWaitEvent(s, ev[1 + g], 0));
+        }
 
-    int t4 = c->timer_begin("msm_reduce", s);
-    uint32_t n_seg = p.W * m1;
-    hipLaunchKernelGGL(msm_reduce1_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, s, buckets, n_seg, p.log_s1, accs, runs);
-    H2_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(msm_reduce2_kernel, dim3(p.W * (D + 1) * 32), dim3(64), 0, s, accs, runs, m1, dplan, Tsum);
-    H2_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(msm_reduce3_kernel, dim3(p.W), dim3(256), 0, s, Tsum, dplan, p.log_s1, wsum);
-    H2_CHECK(hipGetLastError());
-    c->timer_end(t4, s);
+        // ---- s: accumulate this group's buckets (+ over-full buckets)
+        int t2 = c->timer_begin("msm_accum", s);
+        hipLaunchKernelGGL(msm_accum_kernel, dim3((nbg + 255) / 256), dim3(256), 0, s, d_bases, vals1, start, counts, id1 + gb0, nbg, p.heavy_t, p.chunk,
+                           buckets, hcnt + 4 * g, hb + g * max_heavy, hc + g * max_chunks);
+        H2_CHECK(hipGetLastError());
+        c->timer_end(t2, s);
+        int t3 = c->timer_begin("msm_heavy", s);
+        uint32_t hgrid = (uint32_t)(max_chunks < (size_t)c->sm_count * 4 ? max_chunks : (size_t)c->sm_count * 4);
+        hipLaunchKernelGGL(msm_heavy_chunk_kernel, dim3(hgrid), dim3(256), 0, s, d_bases, vals1, hcnt + 4 * g, hc + g * max_chunks, hs + g * max_chunks);
+        H2_CHECK(hipGetLastError());
+        uint32_t fgrid = (uint32_t)(max_heavy < (size_t)c->sm_count ? max_heavy : (size_t)c->sm_count);
+        hipLaunchKernelGGL(msm_heavy_final_kernel, dim3(fgrid), dim3(256), 0, s, hcnt + 4 * g, hb + g * max_heavy, hs + g * max_chunks, buckets);
+        H2_CHECK(hipGetLastError());
+        c->timer_end(t3, s);
+        if (G > 1) {
+            H2_CHECK(hipEventRecord(ev[1 + G + g], s));
+            H2_CHECK(hipStreamWaitEvent(a2, ev[1 + G + g], 0));
+        }
+
+        // ---- aux2: reduce this group's windows
+        int t4 = c->timer_begin("msm_reduce", a2);
+        uint32_t n_seg = Wg * m1;
+        hipLaunchKernelGGL(msm_reduce1_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, a2, buckets + gb0, n_seg, p.log_s1, accs + (size_t)w0 * m1,
+                           runs + (size_t)w0 * m1);
+        H2_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(msm_reduce2_kernel, dim3(Wg * (D + 1) * 32), dim3(64), 0, a2, accs + (size_t)w0 * m1, runs + (size_t)w0 * m1, m1, dplan,
+                           Tsum + (size_t)w0 * (D + 1) * 32);
+        H2_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(msm_reduce3_kernel, dim3(Wg), dim3(256), 0, a2, Tsum + (size_t)w0 * (D + 1) * 32, dplan, p.log_s1, wsum + w0);
+        H2_CHECK(hipGetLastError());
+        c->timer_end(t4, a2);
+    }
+    if (G > 1) {
+        H2_CHECK(hipEventRecord(ev[1 + 2 * G], a2));
+        H2_CHECK(hipStreamWaitEvent(s, ev[1 + 2 * G], 0));
+    }
     c->timer_end(t_all, s);
 
     XYZZ h_ws[MSM_MAX_WINDOWS * 2];
-    if (p.W > MSM_MAX_WINDOWS * 2) {
-        set_error("msm: too many windows");
-        return 1;
-    }
     H2_CHECK(hipMemcpyAsync(h_ws, wsum, (size_t)p.W * sizeof(XYZZ), hipMemcpyDeviceToHost, s));
     H2_CHECK(hipStreamSynchronize(s));
     *h_out = combine_windows(h_ws, p);

@@ -120,6 +120,8 @@ int h2hip_gen_points_device(uint64_t seed, uint64_t start, size_t n, void* d_out
 
 /* MSM window width in bits (2..22); 0 restores the size-based default */
 int h2hip_set_msm_window(uint32_t c);
+/* number of window groups the MSM pipelines over its three streams (1 = no overlap); 0 = size-based default */
+int h2hip_set_msm_groups(uint32_t g);
 /* window width the engine would use for n pairs */
 uint32_t h2hip_get_msm_window(size_t n);
 /* Per-stage HIP-event timers recorded on the stream each kernel group is launched on.

@@ -76,6 +76,18 @@ static void test_field(const char* name) {
         Fu d2i = fu_norm(fu_sub(fu_mul<U>(fu_from_ext(b), one_i), fu_mul<U>(fu_from_ext(a), one_i)));  // I-form (b - a)
         CHECK(fe_eq(fu_canon<U>(fu_mul<U>(d1, d2i)), w2));
         (void)d2;
+        // fused forms: dedicated square, (ab - cd) with one reduction, a^2/2^261 - h
+        {
+            Fu ai = fu_mul<U>(fu_from_ext(a), one_i), bi2 = fu_mul<U>(fu_from_ext(b), one_i);  // I-form a, b
+            Fu dab = fu_sub(ai, bi2);                                                            // signed limbs
+            CHECK(fe_eq(fu_canon<U>(fu_sqr<U>(dab)), fu_canon<U>(fu_mul<U>(dab, dab))));
+            CHECK(fe_eq(fu_mul_canon<U>(fu_sqr<U>(ai), one_e), fe_mul<P>(a, a)));
+            Fe want2 = fe_sub<P>(fe_mul<P>(a, b), fe_mul<P>(fe_sub<P>(a, b), a));              // ab - (a-b)a
+            CHECK(fe_eq(fu_mul_canon<U>(fu_mul_sub<U>(ai, bi2, dab, ai), one_e), want2));
+            Fe want3 = fe_sub<P>(fe_mul<P>(fe_sub<P>(a, b), fe_sub<P>(a, b)), fe_add<P>(a, fe_dbl<P>(b)));  // (a-b)^2 - (a + 2b)
+            Fu hh = fu_add(ai, fu_dbl(bi2));
+            CHECK(fe_eq(fu_mul_canon<U>(fu_sqr_sub<U>(dab, hh), one_e), want3));
+        }
         // zero test
         Fu z = fu_sub(sa, sa);
         CHECK(fu_is_zero_mod_p<U>(z));
