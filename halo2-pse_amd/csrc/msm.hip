@@ -70,33 +70,77 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const Fe* __restrict__ 
     }
 }
 
-// K2a: per bucket (w, b): start = first sorted position of key (w<<c)|b inside window w's segment, count =
-// number of pairs with that key; also the (clamped) size key and identity permutation for the size sort
-__global__ void msm_bounds_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t c, uint32_t gb_base, uint32_t n_buckets,
-                                  uint32_t* __restrict__ start, uint32_t* __restrict__ counts, uint32_t* __restrict__ size_key,
-                                  uint32_t* __restrict__ ids) {
-    uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gb >= n_buckets) return;
-    gb += gb_base;
-    const uint32_t w = gb >> (c - 1), b = gb & ((1u << (c - 1)) - 1);
-    const uint32_t seg = w * n;
-    const uint32_t k0 = (w << c) | b;
-    uint32_t lo = seg, hi = seg + n;
-    while (lo < hi) {
-        uint32_t mid = lo + ((hi - lo) >> 1);
-        if (keys[mid] < k0) lo = mid + 1; else hi = mid;
+// K2a: bucket bounds by boundary detection over the sorted keys (coalesced, no searches): the lane that sees
+// a key change records where the new key's run starts and where the previous key's run ended.  start/end are
+// zeroed beforehand, so an empty bucket reads as [0, 0).
+__global__ void __launch_bounds__(256) msm_bounds_kernel(const uint32_t* __restrict__ keys, size_t e_begin, size_t e_end, uint32_t c,
+                                                         uint32_t* __restrict__ start, uint32_t* __restrict__ end) {
+    const uint32_t NB = 1u << (c - 1), slot_mask = (1u << c) - 1;
+    for (size_t i = e_begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < e_end; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t k = keys[i];
+        const bool first = (i == e_begin);
+        const uint32_t kp = first ? 0xffffffffu : keys[i - 1];
+        if (first || kp != k) {
+            if ((k & slot_mask) < NB) start[((k >> c) << (c - 1)) | (k & slot_mask)] = (uint32_t)i;
+            if (!first && (kp & slot_mask) < NB) end[((kp >> c) << (c - 1)) | (kp & slot_mask)] = (uint32_t)i;
+        }
+        if (i + 1 == e_end && (k & slot_mask) < NB) end[((k >> c) << (c - 1)) | (k & slot_mask)] = (uint32_t)(i + 1);
     }
-    const uint32_t first = lo;
-    hi = seg + n;
-    while (lo < hi) {
-        uint32_t mid = lo + ((hi - lo) >> 1);
-        if (keys[mid] <= k0) lo = mid + 1; else hi = mid;
+}
+
+// K2b/K2c: order the buckets by size (descending, in 256 classes of width 2^bin_shift) with a counting sort, so that
+// the 64 lanes of an accumulate wave get buckets of near-equal size.  hist[0..256) = class counts, hist[256..512)
+// = per-class cursors; both zeroed beforehand.
+__device__ __forceinline__ uint32_t size_class(uint32_t cnt, uint32_t bin_shift) {
+    uint32_t b = cnt >> bin_shift;
+    return 255u - (b < 255u ? b : 255u);  // big buckets first
+}
+
+__global__ void __launch_bounds__(256) msm_bucket_hist_kernel(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t gb_base,
+                                                              uint32_t n_buckets, uint32_t bin_shift, uint32_t* __restrict__ counts,
+                                                              uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_buckets) {
+        uint32_t gb = gb_base + t;
+        uint32_t cnt = end[gb] - start[gb];
+        counts[gb] = cnt;
+        atomicAdd(&lh[size_class(cnt, bin_shift)], 1u);
     }
-    const uint32_t cnt = lo - first;
-    start[gb] = first;
-    counts[gb] = cnt;
-    size_key[gb] = cnt < 0xffffu ? cnt : 0xffffu;
-    ids[gb] = gb;
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(256) msm_bucket_scatter_kernel(const uint32_t* __restrict__ counts, uint32_t gb_base, uint32_t n_buckets,
+                                                                 uint32_t bin_shift, uint32_t* __restrict__ hist, uint32_t* __restrict__ perm) {
+    __shared__ uint32_t scan[256], lh[256], lbase[256];
+    // exclusive scan of the 256 class counts (every block repeats it: 256 values)
+    uint32_t v = hist[threadIdx.x];
+    scan[threadIdx.x] = v;
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        uint32_t add = threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
+        __syncthreads();
+        scan[threadIdx.x] += add;
+        __syncthreads();
+    }
+    const uint32_t excl = scan[threadIdx.x] - v;
+    __syncthreads();
+    scan[threadIdx.x] = excl;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cls = 0, rank = 0;
+    const bool live = t < n_buckets;
+    if (live) {
+        cls = size_class(counts[gb_base + t], bin_shift);
+        rank = atomicAdd(&lh[cls], 1u);
+    }
+    __syncthreads();
+    if (lh[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&hist[256 + threadIdx.x], lh[threadIdx.x]);
+    __syncthreads();
+    if (live) perm[scan[cls] + lbase[cls] + rank] = gb_base + t;
 }
 
 struct HeavyBucket {
@@ -277,11 +321,12 @@ static MsmPlan make_plan(size_t n) {
     } else {
         uint32_t lg = 0;
         while (((size_t)1 << (lg + 1)) <= n) lg++;
-        // enough buckets to fill 256 CUs, few enough that the reduction stays small
-        if (lg <= 8) c = 6;
-        else if (lg <= 12) c = 9;
-        else if (lg <= 16) c = 12;
-        else if (lg <= 19) c = 14;
+        // enough buckets to fill 256 CUs, few enough that the reduction stays small, and 254 mod c large so
+        // that the top window is not a handful of over-full buckets
+        if (lg <= 8) c = 7;
+        else if (lg <= 12) c = 10;
+        else if (lg <= 16) c = 13;
+        else if (lg <= 19) c = 15;
         else c = 16;
     }
     if (c < 2) c = 2;
@@ -290,9 +335,11 @@ static MsmPlan make_plan(size_t n) {
     p.W = 254 / c + 1;
     p.NB = 1u << (c - 1);
     p.log_s1 = (c - 1) < 3 ? (c - 1) : 3;  // short chains when there are few buckets, 8-bucket segments when many
-    size_t avg = (n * p.W) / ((size_t)p.W * p.NB) + 1;
-    size_t t = 4 * avg;
-    if (t < 2048) t = 2048;
+    // A lone lane adds ~6 us per pair, and the kernel cannot finish faster than 2 * n*W / 65536 add-times
+    // anyway (64 lanes x 1024 SIMDs): buckets above that go to the chunked path, or one lane's chain
+    // (e.g. the few buckets of a narrow top window) sets the kernel's duration.
+    size_t t = (n * p.W) / 32768;
+    if (t < 32) t = 32;
     p.heavy_t = (uint32_t)t;
     p.chunk = 4096;
     return p;
@@ -353,13 +400,10 @@ static int msm_device_chunk(Ctx* c, const Fe* d_scalars, const Affine* d_bases, 
     size_t o_keys0 = carve(E * 4), o_keys1 = carve(E * 4), o_vals0 = carve(E * 4), o_vals1 = carve(E * 4);
     size_t o_cub = carve(cub_bytes);
     size_t o_start = carve(((size_t)n_buckets + 2) * 4);
+    size_t o_end = carve(((size_t)n_buckets + 2) * 4);  // directly after start: one memset clears both
     size_t o_counts = carve((size_t)n_buckets * 4);
-    size_t cub2_bytes = 0;
-    H2_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, cub2_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                                          (uint32_t*)nullptr, (int)nbg_max, 0, 16, s));
-    size_t o_cnt0 = carve((size_t)n_buckets * 4), o_cnt1 = carve((size_t)n_buckets * 4);
-    size_t o_id0 = carve((size_t)n_buckets * 4), o_id1 = carve((size_t)n_buckets * 4);
-    size_t o_cub2 = carve(cub2_bytes);
+    size_t o_perm = carve((size_t)n_buckets * 4);
+    size_t o_hist = carve((size_t)G * 512 * 4);
     size_t o_buckets = carve((size_t)n_buckets * sizeof(XYZZu));
     size_t o_acc = carve((size_t)p.W * m1 * sizeof(XYZZu)), o_run = carve((size_t)p.W * m1 * sizeof(XYZZu));
     size_t o_wsum = carve((size_t)p.W * sizeof(XYZZ));
@@ -389,8 +433,12 @@ static int msm_device_chunk(Ctx* c, const Fe* d_scalars, const Affine* d_bases, 
     uint32_t *vals0 = (uint32_t*)(base + o_vals0), *vals1 = (uint32_t*)(base + o_vals1);
     uint32_t* start = (uint32_t*)(base + o_start);
     uint32_t* counts = (uint32_t*)(base + o_counts);
-    uint32_t *cnt0 = (uint32_t*)(base + o_cnt0), *cnt1 = (uint32_t*)(base + o_cnt1);
-    uint32_t *id0 = (uint32_t*)(base + o_id0), *id1 = (uint32_t*)(base + o_id1);
+    uint32_t* endp = (uint32_t*)(base + o_end);
+    uint32_t* perm = (uint32_t*)(base + o_perm);
+    uint32_t* hist = (uint32_t*)(base + o_hist);
+    // size classes: width 2^bin_shift pairs, the mean bucket size lands in classes 50..100 (of 256)
+    uint32_t bin_shift = 0;
+    while (((n / p.NB) >> bin_shift) > 100) bin_shift++;
     XYZZu* buckets = (XYZZu*)(base + o_buckets);
     XYZZu *accs = (XYZZu*)(base + o_acc), *runs = (XYZZu*)(base + o_run);
     XYZZ* wsum = (XYZZ*)(base + o_wsum);
@@ -407,6 +455,8 @@ static int msm_device_chunk(Ctx* c, const Fe* d_scalars, const Affine* d_bases, 
     int t_all = c->timer_begin("msm_total", s);
     int t0 = c->timer_begin("msm_digits", s);
     H2_CHECK(hipMemsetAsync(hcnt, 0, 16 * G, s));
+    H2_CHECK(hipMemsetAsync(start, 0, o_counts - o_start, s));  // start[] and end[]
+    H2_CHECK(hipMemsetAsync(hist, 0, (size_t)G * 512 * 4, s));
     hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, d_scalars, (uint32_t)n, p.c, p.W, p.NB, keys0, vals0);
     H2_CHECK(hipGetLastError());
     c->timer_end(t0, s);
@@ -430,9 +480,16 @@ static int msm_device_chunk(Ctx* c, const Fe* d_scalars, const Affine* d_bases, 
         } else {
             H2_CHECK(hipcub::DeviceRadixSort::SortPairs(base + o_cub, cub_bytes, keys0 + e0, keys1 + e0, vals0 + e0, vals1 + e0, (int)Eg, 0, end_bit, a1));
         }
-        hipLaunchKernelGGL(msm_bounds_kernel, dim3((nbg + 255) / 256), dim3(256), 0, a1, keys1, (uint32_t)n, p.c, gb0, nbg, start, counts, cnt0, id0);
+        {
+            size_t blocks = (Eg + 255) / 256;
+            uint32_t grid = (uint32_t)(blocks < (size_t)c->sm_count * 16 ? blocks : (size_t)c->sm_count * 16);
+            hipLaunchKernelGGL(msm_bounds_kernel, dim3(grid), dim3(256), 0, a1, keys1, e0, e0 + Eg, p.c, start, endp);
+            H2_CHECK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(msm_bucket_hist_kernel, dim3((nbg + 255) / 256), dim3(256), 0, a1, start, endp, gb0, nbg, bin_shift, counts, hist + 512 * g);
         H2_CHECK(hipGetLastError());
-        H2_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(base + o_cub2, cub2_bytes, cnt0 + gb0, cnt1 + gb0, id0 + gb0, id1 + gb0, (int)nbg, 0, 16, a1));
+        hipLaunchKernelGGL(msm_bucket_scatter_kernel, dim3((nbg + 255) / 256), dim3(256), 0, a1, counts, gb0, nbg, bin_shift, hist + 512 * g, perm + gb0);
+        H2_CHECK(hipGetLastError());
         c->timer_end(t1, a1);
         if (G > 1) {
             H2_CHECK(hipEventRecord(ev[1 + g], a1));
@@ -441,7 +498,7 @@ static int msm_device_chunk(Ctx* c, const Fe* d_scalars, const Affine* d_bases, 
 
         // ---- s: accumulate this group's buckets (+ over-full buckets)
         int t2 = c->timer_begin("msm_accum", s);
-        hipLaunchKernelGGL(msm_accum_kernel, dim3((nbg + 255) / 256), dim3(256), 0, s, d_bases, vals1, start, counts, id1 + gb0, nbg, p.heavy_t, p.chunk,
+        hipLaunchKernelGGL(msm_accum_kernel, dim3((nbg + 255) / 256), dim3(256), 0, s, d_bases, vals1, start, counts, perm + gb0, nbg, p.heavy_t, p.chunk,
                            buckets, hcnt + 4 * g, hb + g * max_heavy, hc + g * max_chunks);
         H2_CHECK(hipGetLastError());
         c->timer_end(t2, s);
