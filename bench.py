@@ -56,7 +56,9 @@ def main():
     ap.add_argument("--log-n", type=int, default=20, help="pairs per GPU = 2^log_n")
     ap.add_argument("--ntt-log-n", type=int, default=22)
     ap.add_argument("--window", type=int, default=0, help="MSM window bits (0 = engine default)")
-    ap.add_argument("--groups", type=int, default=0, help="MSM window groups pipelined over streams (0 = engine default)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
+                    "N > 1 path on a single-GPU box, where every rank then uses cuda:0)")
+    ap.add_argument("--batch", type=int, default=8, help="also time a pipelined batch of this many MSMs (extra key; 0/1 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     args = ap.parse_args()
@@ -70,19 +72,22 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libhalo2hip has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
+    gather_dev = dev if args.backend == "nccl" else None
 
     h2 = load_pkg()
     from importlib import import_module
     h2dist = import_module("halo2_pse_amd.dist")
-    h2.init(local_rank)
+    h2.init(dev_index)
     if args.window:
         h2.set_msm_window(args.window)
-    if args.groups:
-        h2.set_msm_groups(args.groups)
 
     n = 1 << args.log_n
     c = h2.get_msm_window(n)
@@ -95,7 +100,7 @@ def main():
     def step():
         part = h2.msm_device(d_scalars, d_points)
         if world > 1:
-            return h2dist.allgather_fold(part, h2, device=dev)
+            return h2dist.allgather_fold(part, h2, device=gather_dev)
         return part
 
     def sync_all():
@@ -115,7 +120,7 @@ def main():
     elapsed = time.perf_counter() - t0
     h2.profile_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -123,6 +128,23 @@ def main():
     for st in ("msm_total", "msm_digits", "msm_sort", "msm_accum", "msm_heavy", "msm_reduce"):
         ms, cnt = h2.profile_get(st)
         stages[st] = ms / cnt if cnt else None
+
+    # ---- batched commit: B MSMs over the same bases in one pipelined call, rank 0 only ----
+    batched = None
+    if rank == 0 and world == 1 and args.batch > 1 and args.log_n <= 22:
+        B = args.batch
+        cols = [h2.gen_scalars_device(0x5EED0001, n, start=(j + 1) * n, device=dev) for j in range(B)]
+        h2.msm_batch_device(cols, d_points)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            h2.msm_batch_device(cols, d_points)
+        torch.cuda.synchronize()
+        tb = (time.perf_counter() - t1) / (reps * B)
+        batched = {"count": B, "ms_per_msm": tb * 1e3, "value": n * W / tb, "unit": "G1-adds/s",
+                   "note": "h2hip_msm_bn254_batch_device: whole MSMs pipelined over three streams"}
+        del cols
 
     # ---- NTT leg (BASELINE.json configs[2]: k = 22 NTT + iNTT), outside the MSM timed region ----
     ntt = None
@@ -211,6 +233,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "parity_vs_cpu": parity,
+            "batched": batched,
             "ntt": ntt,
         }
         print(json.dumps(out))

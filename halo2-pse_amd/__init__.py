@@ -110,6 +110,21 @@ def best_multiexp(coeffs, bases):
     return out
 
 
+def best_multiexp_batch(coeffs_list, bases):
+    """`len(coeffs_list)` MSMs over the same bases (the back-to-back commits of plonk/prover.rs:361-365);
+    returns (count, 12) uint64 Jacobian results."""
+    bases = _u64(bases, 8)
+    cols = [_u64(c, 4) for c in coeffs_list]
+    n = bases.shape[0]
+    for c in cols:
+        assert c.shape[0] == n  # arithmetic.rs:133
+    count = len(cols)
+    ptrs = (ctypes.c_void_p * count)(*[c.ctypes.data for c in cols])
+    out = np.zeros((count, 12), dtype=np.uint64)
+    _check(lib().h2hip_msm_bn254_batch(ptrs, _p(bases), ctypes.c_size_t(n), ctypes.c_size_t(count), _p(out)), "h2hip_msm_bn254_batch")
+    return out
+
+
 def best_fft(a, omega, log_n):
     """halo2_proofs::arithmetic::best_fft (arithmetic.rs:171-234) for G = bn256::Fr; in place on `a`."""
     assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
@@ -208,6 +223,10 @@ class ParamsKZG:
         _check(lib().h2hip_msm_bn254(_p(poly), _p(self.g_lagrange), ctypes.c_size_t(size), _p(out)), "h2hip_msm_bn254")
         return out
 
+    def commit_lagrange_many(self, polys):
+        """the advice-column loop of plonk/prover.rs:361-365 as one pipelined batch"""
+        return best_multiexp_batch(polys, self.g_lagrange)
+
     def commit(self, poly, blind=None):
         poly = _u64(poly, 4)
         size = poly.shape[0]
@@ -240,6 +259,18 @@ def msm_device(d_scalars, d_bases, n=None):
     n = nb // 32 if n is None else int(n)
     out = np.zeros(12, dtype=np.uint64)
     _check(lib().h2hip_msm_bn254_device(_dptr(d_scalars), _dptr(d_bases), ctypes.c_size_t(n), _p(out), _stream()), "h2hip_msm_bn254_device")
+    return out
+
+
+def msm_batch_device(d_scalars_list, d_bases, n=None):
+    """count MSMs over the same device-resident bases; returns (count, 12) uint64"""
+    count = len(d_scalars_list)
+    if n is None:
+        n = d_scalars_list[0].numel() * d_scalars_list[0].element_size() // 32
+    ptrs = (ctypes.c_void_p * count)(*[t.data_ptr() for t in d_scalars_list])
+    out = np.zeros((count, 12), dtype=np.uint64)
+    _check(lib().h2hip_msm_bn254_batch_device(ptrs, _dptr(d_bases), ctypes.c_size_t(n), ctypes.c_size_t(count), _p(out), _stream()),
+           "h2hip_msm_bn254_batch_device")
     return out
 
 
@@ -287,10 +318,6 @@ def to_numpy_u64(t):
 # ------------------------------------------------------------------ tuning / measurement
 def set_msm_window(c):
     _check(lib().h2hip_set_msm_window(ctypes.c_uint32(c)), "h2hip_set_msm_window")
-
-
-def set_msm_groups(g):
-    _check(lib().h2hip_set_msm_groups(ctypes.c_uint32(g)), "h2hip_set_msm_groups")
 
 
 def get_msm_window(n):

@@ -11,7 +11,8 @@ namespace h2 {
 int gen_scalars_device(uint64_t seed, uint64_t start, size_t n, Fe* d_out, hipStream_t s);
 int gen_points_device(uint64_t seed, uint64_t start, size_t n, Affine* d_out, hipStream_t s);
 void msm_set_window(uint32_t c);
-void msm_set_groups(uint32_t g);
+void msm_set_reserved_cus(uint32_t k);
+uint32_t msm_get_reserved_cus();
 uint32_t msm_get_window(size_t n);
 
 static thread_local char g_err[512] = "";
@@ -40,6 +41,31 @@ int DevBuf::ensure(size_t bytes) {
     }
     cap = want;
     return 0;
+}
+
+int HostBuf::ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) {
+        H2_CHECK(hipDeviceSynchronize());
+        H2_CHECK(hipHostFree(p));
+        p = nullptr;
+        cap = 0;
+    }
+    size_t want = bytes * 2 + 4096;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        p = nullptr;
+        set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return H2HIP_ENOMEM;
+    }
+    cap = want;
+    return 0;
+}
+
+void HostBuf::release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
 }
 
 void DevBuf::release() {
@@ -114,9 +140,35 @@ int Ctx::ws_release(hipStream_t s) {
     return 0;
 }
 
+// aux1 (stage A) and aux2 (stage C) run on a reserved slice of the CUs, aux_b (stage B) on the rest.  The slice
+// takes K/16 of every 16 consecutive CU ids, so it is spread over all XCDs whatever the id -> XCD mapping is.
 int Ctx::ensure_aux(size_t n_events) {
-    if (!aux1) H2_CHECK(hipStreamCreateWithFlags(&aux1, hipStreamNonBlocking));
-    if (!aux2) H2_CHECK(hipStreamCreateWithFlags(&aux2, hipStreamNonBlocking));
+    const uint32_t K = msm_get_reserved_cus();
+    if (aux1 && aux_reserved != K) {
+        H2_CHECK(hipDeviceSynchronize());
+        (void)hipStreamDestroy(aux1);
+        (void)hipStreamDestroy(aux2);
+        (void)hipStreamDestroy(aux_b);
+        aux1 = aux2 = aux_b = nullptr;
+    }
+    if (!aux1) {
+        const int n_cu = sm_count;
+        const uint32_t words = (uint32_t)((n_cu + 31) / 32);
+        std::vector<uint32_t> mask_ac(words, 0), mask_b(words, 0);
+        const uint32_t per16 = (K * 16 + (uint32_t)n_cu - 1) / (uint32_t)n_cu;  // reserved ids out of every 16
+        for (int i = 0; i < n_cu; i++) {
+            bool reserved = K > 0 && (uint32_t)(i % 16) >= 16 - per16;
+            (reserved ? mask_ac : mask_b)[i / 32] |= 1u << (i % 32);
+        }
+        if (K == 0 || per16 >= 16) {  // no partition: every stream sees every CU
+            for (auto& w : mask_ac) w = 0xffffffffu;
+            for (auto& w : mask_b) w = 0xffffffffu;
+        }
+        H2_CHECK(hipExtStreamCreateWithCUMask(&aux1, words, mask_ac.data()));
+        H2_CHECK(hipExtStreamCreateWithCUMask(&aux2, words, mask_ac.data()));
+        H2_CHECK(hipExtStreamCreateWithCUMask(&aux_b, words, mask_b.data()));
+        aux_reserved = K;
+    }
     while (aux_events.size() < n_events) {
         hipEvent_t e;
         H2_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -260,9 +312,12 @@ void h2hip_shutdown(void) {
     c->pinned.clear();
     c->ntt_ws.release();
     c->ntt_io.release();
-    c->msm_scalars.release();
+    for (int k = 0; k < 3; k++) {
+        c->msm_scalars[k].release();
+        c->msm_slot[k].release();
+    }
     c->msm_bases.release();
-    c->msm_ws.release();
+    c->host_ws.release();
     c->misc.release();
     (void)hipStreamDestroy(c->stream);
     c->stream = nullptr;
@@ -270,7 +325,8 @@ void h2hip_shutdown(void) {
     c->aux_events.clear();
     if (c->aux1) (void)hipStreamDestroy(c->aux1);
     if (c->aux2) (void)hipStreamDestroy(c->aux2);
-    c->aux1 = c->aux2 = nullptr;
+    if (c->aux_b) (void)hipStreamDestroy(c->aux_b);
+    c->aux1 = c->aux2 = c->aux_b = nullptr;
     if (c->ws_event) (void)hipEventDestroy(c->ws_event);
     c->ws_event = nullptr;
     c->ws_used = false;
@@ -301,35 +357,68 @@ int h2hip_msm_bn254_device(const void* d_scalars, const void* d_bases_xy, size_t
     return 0;
 }
 
-int h2hip_msm_bn254(const uint64_t* scalars, const uint64_t* bases_xy, size_t n, uint64_t out_xyz[12]) {
-    if (!out_xyz || (n && (!scalars || !bases_xy))) {
-        set_error("msm: null argument");
-        return H2HIP_EINVAL;
-    }
+static int msm_host_common(const uint64_t* const* scalars, const uint64_t* bases_xy, size_t n, size_t count, uint64_t* out_xyz) {
     Entry en;
     if (en.rc) return en.rc;
     Ctx* c = en.c;
-    if (n == 0) {
-        xyzz_to_out(xyzz_identity(), out_xyz);
+    if (n == 0 || count == 0) {
+        for (size_t j = 0; j < count; j++) xyzz_to_out(xyzz_identity(), out_xyz + 12 * j);
         return 0;
     }
-    int rc = c->msm_scalars.ensure(n * sizeof(Fe));
-    if (rc) return rc;
-    H2_CHECK(hipMemcpyAsync(c->msm_scalars.p, scalars, n * sizeof(Fe), hipMemcpyHostToDevice, c->stream));
     const Affine* d_bases = nullptr;
     auto it = c->pinned.find((const void*)bases_xy);
     if (it != c->pinned.end() && it->second.n >= n) {
         d_bases = (const Affine*)it->second.d;
     } else {
-        rc = c->msm_bases.ensure(n * sizeof(Affine));
+        int rc = c->msm_bases.ensure(n * sizeof(Affine));
         if (rc) return rc;
         H2_CHECK(hipMemcpyAsync(c->msm_bases.p, bases_xy, n * sizeof(Affine), hipMemcpyHostToDevice, c->stream));
         d_bases = (const Affine*)c->msm_bases.p;
     }
-    XYZZ r;
-    rc = msm_device(c, (const Fe*)c->msm_scalars.p, d_bases, n, &r, c->stream);
+    std::vector<XYZZ> r(count);
+    int rc = msm_batch_device(c, (const Fe* const*)scalars, true, d_bases, n, count, r.data(), c->stream);
     if (rc) return rc;
-    xyzz_to_out(r, out_xyz);
+    for (size_t j = 0; j < count; j++) xyzz_to_out(r[j], out_xyz + 12 * j);
+    return 0;
+}
+
+int h2hip_msm_bn254(const uint64_t* scalars, const uint64_t* bases_xy, size_t n, uint64_t out_xyz[12]) {
+    if (!out_xyz || (n && (!scalars || !bases_xy))) {
+        set_error("msm: null argument");
+        return H2HIP_EINVAL;
+    }
+    return msm_host_common(&scalars, bases_xy, n, 1, out_xyz);
+}
+
+int h2hip_msm_bn254_batch(const uint64_t* const* scalars, const uint64_t* bases_xy, size_t n, size_t count, uint64_t* out_xyz) {
+    if ((count && (!out_xyz || !scalars)) || (n && count && !bases_xy)) {
+        set_error("msm_batch: null argument");
+        return H2HIP_EINVAL;
+    }
+    for (size_t j = 0; j < count; j++)
+        if (n && !scalars[j]) {
+            set_error("msm_batch: scalars[%zu] is null", j);
+            return H2HIP_EINVAL;
+        }
+    return msm_host_common(scalars, bases_xy, n, count, out_xyz);
+}
+
+int h2hip_msm_bn254_batch_device(const void* const* d_scalars, const void* d_bases_xy, size_t n, size_t count, uint64_t* out_xyz, void* stream) {
+    if ((count && (!out_xyz || !d_scalars)) || (n && count && !d_bases_xy)) {
+        set_error("msm_batch: null argument");
+        return H2HIP_EINVAL;
+    }
+    for (size_t j = 0; j < count; j++)
+        if (n && !d_scalars[j]) {
+            set_error("msm_batch: d_scalars[%zu] is null", j);
+            return H2HIP_EINVAL;
+        }
+    Entry en;
+    if (en.rc) return en.rc;
+    std::vector<XYZZ> r(count);
+    int rc = msm_batch_device(en.c, (const Fe* const*)d_scalars, false, (const Affine*)d_bases_xy, n, count, r.data(), (hipStream_t)stream);
+    if (rc) return rc;
+    for (size_t j = 0; j < count; j++) xyzz_to_out(r[j], out_xyz + 12 * j);
     return 0;
 }
 
@@ -543,12 +632,9 @@ int h2hip_set_msm_window(uint32_t c) {
 
 uint32_t h2hip_get_msm_window(size_t n) { return msm_get_window(n); }
 
-int h2hip_set_msm_groups(uint32_t g) {
-    if (g > 16) {
-        set_error("msm groups must be 0 (auto) or 1..16");
-        return H2HIP_EINVAL;
-    }
-    msm_set_groups(g);
+// undocumented tuning knob (not in the public header): CUs reserved for the sort / reduce stages of a batch
+int h2hip_debug_set_reserved_cus(uint32_t k) {
+    msm_set_reserved_cus(k);
     return 0;
 }
 

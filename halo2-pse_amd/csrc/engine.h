@@ -33,6 +33,14 @@ struct DevBuf {
     void release();
 };
 
+// grow-only pinned host buffer
+struct HostBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);
+    void release();
+};
+
 struct TwiddleKey {
     uint32_t omega[8];
     uint32_t log_n;
@@ -67,7 +75,8 @@ struct Ctx {
     bool ready = false;
     hipStream_t stream = nullptr;  // the engine's own stream (host-pointer entry points)
     std::recursive_mutex mu;       // serialises entry points: re-entrant callers (rayon workers) are safe
-    DevBuf ntt_ws, ntt_io, msm_scalars, msm_bases, msm_ws, misc;
+    DevBuf ntt_ws, ntt_io, msm_scalars[3], msm_bases, msm_slot[3], misc;
+    HostBuf host_ws;               // pinned host memory for the window sums coming back
     std::map<TwiddleKey, TwiddleTable> twiddles;
     std::map<const void*, PinnedBases> pinned;
     // profiling
@@ -86,7 +95,8 @@ struct Ctx {
     int ws_acquire(hipStream_t s);
     int ws_release(hipStream_t s);
     // internal streams + events for the MSM's window-group pipeline
-    hipStream_t aux1 = nullptr, aux2 = nullptr;
+    hipStream_t aux1 = nullptr, aux2 = nullptr, aux_b = nullptr;
+    uint32_t aux_reserved = 0xffffffffu;  // CU reservation the aux streams were created with
     std::vector<hipEvent_t> aux_events;
     int ensure_aux(size_t n_events);
 };
@@ -107,5 +117,7 @@ int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttSca
 
 // msm.hip
 int msm_device(Ctx* c, const Fe* d_scalars, const Affine* d_bases, size_t n, XYZZ* h_out, hipStream_t s);
+int msm_batch_device(Ctx* c, const Fe* const* scalars, bool scalars_on_host, const Affine* d_bases, size_t n, size_t count, XYZZ* h_out,
+                     hipStream_t s);
 
 }  // namespace h2

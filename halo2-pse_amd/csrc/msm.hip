@@ -21,6 +21,8 @@
 #include <hipcub/hipcub.hpp>
 #include <string.h>
 
+#include <vector>
+
 #include "engine.h"
 #include "host64.h"
 
@@ -309,9 +311,10 @@ __global__ void __launch_bounds__(256) msm_reduce3_kernel(const XYZZu* __restric
 }
 
 static uint32_t g_window_override = 0;
-static uint32_t g_groups_override = 0;
+static uint32_t g_reserved_cus = 0;  // measured on MI355X: every partition (16..96 CUs) was slower than none
+void msm_set_reserved_cus(uint32_t k) { g_reserved_cus = k; }
+uint32_t msm_get_reserved_cus() { return g_reserved_cus; }
 void msm_set_window(uint32_t c) { g_window_override = c; }
-void msm_set_groups(uint32_t g) { g_groups_override = g; }
 
 static MsmPlan make_plan(size_t n) {
     MsmPlan p;
@@ -359,202 +362,268 @@ static XYZZ combine_windows(const XYZZ* ws, const MsmPlan& p) {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// One MSM of n <= 2^26 pairs.  The W windows are processed in G groups pipelined over three streams so
-// that the memory-bound sort of group g+1 and the latency-bound reduction of group g-1 run under the
-// VALU-bound accumulation of group g:
-//   aux1:  sort(0) bounds(0) | sort(1) bounds(1) | ...
-//   s   :  digits | accum(0) heavy(0) | accum(1) heavy(1) | ...                 | copy-out
-//   aux2:                    | reduce(0)           | reduce(1) ...  | reduce(G-1)
-static int msm_device_chunk(Ctx* c, const Fe* d_scalars, const Affine* d_bases, size_t n, XYZZ* h_out, hipStream_t s) {
+// Workspace layout of one in-flight MSM ("slot")
+struct MsmLayout {
+    MsmPlan p;
+    DigitPlan dplan;
+    size_t n, E;
+    uint32_t n_buckets, m1, D, bin_shift;
+    bool per_window_sort;
+    int end_bit;
+    size_t cub_bytes, max_chunks, max_heavy;
+    size_t o_keys0, o_keys1, o_vals0, o_vals1, o_cub, o_start, o_end, o_counts, o_perm, o_hist, o_buckets, o_acc, o_run, o_wsum, o_T, o_hcnt,
+        o_hb, o_hc, o_hs, total;
+};
+
+static int msm_layout(size_t n, hipStream_t s, MsmLayout* L) {
     MsmPlan p = make_plan(n);
-    const size_t E = n * p.W;
-    if (E >= ((size_t)1 << 31)) {
-        set_error("msm: n*W = %zu pairs exceeds the 2^31 sort limit (window override too small?)", E);
+    L->p = p;
+    L->n = n;
+    L->E = n * p.W;
+    if (L->E >= ((size_t)1 << 31)) {
+        set_error("msm: n*W = %zu pairs exceeds the 2^31 sort limit (window override too small?)", L->E);
         return 1;
     }
     if (p.W > MSM_MAX_WINDOWS * 2) {
         set_error("msm: too many windows");
         return 1;
     }
-    const uint32_t n_buckets = p.W * p.NB;
-    const uint32_t m1 = p.NB >> p.log_s1;
-    const uint32_t G = (g_groups_override ? g_groups_override : 1u);
-    const uint32_t wpg = (p.W + G - 1) / G;  // windows per group
-
-    // Small inputs: one radix sort per group over (window, slot); large inputs: one sort per window on the slot
-    // bits only (the pairs are already window-major) -- 2 passes of 8 bits instead of 3.
-    const bool per_window_sort = n >= ((size_t)1 << 22);
-    size_t cub_bytes = 0;
+    L->n_buckets = p.W * p.NB;
+    L->m1 = p.NB >> p.log_s1;
+    // Small inputs: one radix sort over (window, slot); large inputs: one sort per window on the slot bits only
+    // (the pairs are already window-major) -- 2 passes of 8 bits instead of 3 over all n*W pairs.
+    L->per_window_sort = n >= ((size_t)1 << 22);
     uint32_t wbits = 0;
     while ((1u << wbits) < p.W) wbits++;
-    const int end_bit = per_window_sort ? (int)p.c : (int)(p.c + wbits);
-    const size_t Eg_max = (size_t)wpg * n;
-    H2_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                                (uint32_t*)nullptr, (int)(per_window_sort ? n : Eg_max), 0, end_bit, s));
-    const uint32_t nbg_max = wpg * p.NB;
-    const size_t max_chunks = Eg_max / p.chunk + Eg_max / p.heavy_t + 16;  // per group: sum of ceil(cnt/chunk) over buckets with cnt > heavy_t
-    const size_t max_heavy = Eg_max / p.heavy_t + 16;
-    // carve the workspace
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    size_t o_keys0 = carve(E * 4), o_keys1 = carve(E * 4), o_vals0 = carve(E * 4), o_vals1 = carve(E * 4);
-    size_t o_cub = carve(cub_bytes);
-    size_t o_start = carve(((size_t)n_buckets + 2) * 4);
-    size_t o_end = carve(((size_t)n_buckets + 2) * 4);  // directly after start: one memset clears both
-    size_t o_counts = carve((size_t)n_buckets * 4);
-    size_t o_perm = carve((size_t)n_buckets * 4);
-    size_t o_hist = carve((size_t)G * 512 * 4);
-    size_t o_buckets = carve((size_t)n_buckets * sizeof(XYZZu));
-    size_t o_acc = carve((size_t)p.W * m1 * sizeof(XYZZu)), o_run = carve((size_t)p.W * m1 * sizeof(XYZZu));
-    size_t o_wsum = carve((size_t)p.W * sizeof(XYZZ));
+    L->end_bit = L->per_window_sort ? (int)p.c : (int)(p.c + wbits);
+    L->cub_bytes = 0;
+    H2_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, L->cub_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                                (uint32_t*)nullptr, (int)(L->per_window_sort ? n : L->E), 0, L->end_bit, s));
+    L->max_chunks = L->E / p.chunk + L->E / p.heavy_t + 16;  // sum of ceil(cnt/chunk) over buckets with cnt > heavy_t
+    L->max_heavy = L->E / p.heavy_t + 16;
     // digits of the segment index t < m1: ceil(bits / 5) digits of near-equal width
     uint32_t tbits = 0;
-    while ((1u << tbits) < m1) tbits++;
-    DigitPlan dplan;
-    memset(&dplan, 0, sizeof(dplan));
-    uint32_t D = tbits ? (tbits + 4) / 5 : 1;
-    dplan.D = D;
-    for (uint32_t d = 0, pos = 0; d < D; d++) {
-        uint32_t wd = tbits / D + (d < tbits % D ? 1 : 0);
-        dplan.width[d] = wd;
-        dplan.shift[d] = pos;
+    while ((1u << tbits) < L->m1) tbits++;
+    memset(&L->dplan, 0, sizeof(L->dplan));
+    L->D = tbits ? (tbits + 4) / 5 : 1;
+    L->dplan.D = L->D;
+    for (uint32_t d = 0, pos = 0; d < L->D; d++) {
+        uint32_t wd = tbits / L->D + (d < tbits % L->D ? 1 : 0);
+        L->dplan.width[d] = wd;
+        L->dplan.shift[d] = pos;
         pos += wd;
     }
-    size_t o_T = carve((size_t)p.W * (D + 1) * 32 * sizeof(XYZZu));
-    size_t o_hcnt = carve(16 * G);
-    size_t o_hb = carve(G * max_heavy * sizeof(HeavyBucket)), o_hc = carve(G * max_chunks * sizeof(HeavyChunk));
-    size_t o_hs = carve(G * max_chunks * sizeof(XYZZu));
-    int rc = c->msm_ws.ensure(off);
-    if (rc) return rc;
-    rc = c->ensure_aux(3 * G + 2);
-    if (rc) return rc;
-    char* base = (char*)c->msm_ws.p;
-    uint32_t *keys0 = (uint32_t*)(base + o_keys0), *keys1 = (uint32_t*)(base + o_keys1);
-    uint32_t *vals0 = (uint32_t*)(base + o_vals0), *vals1 = (uint32_t*)(base + o_vals1);
-    uint32_t* start = (uint32_t*)(base + o_start);
-    uint32_t* counts = (uint32_t*)(base + o_counts);
-    uint32_t* endp = (uint32_t*)(base + o_end);
-    uint32_t* perm = (uint32_t*)(base + o_perm);
-    uint32_t* hist = (uint32_t*)(base + o_hist);
     // size classes: width 2^bin_shift pairs, the mean bucket size lands in classes 50..100 (of 256)
-    uint32_t bin_shift = 0;
-    while (((n / p.NB) >> bin_shift) > 100) bin_shift++;
-    XYZZu* buckets = (XYZZu*)(base + o_buckets);
-    XYZZu *accs = (XYZZu*)(base + o_acc), *runs = (XYZZu*)(base + o_run);
-    XYZZ* wsum = (XYZZ*)(base + o_wsum);
-    XYZZu* Tsum = (XYZZu*)(base + o_T);
-    uint32_t* hcnt = (uint32_t*)(base + o_hcnt);
-    HeavyBucket* hb = (HeavyBucket*)(base + o_hb);
-    HeavyChunk* hc = (HeavyChunk*)(base + o_hc);
-    XYZZu* hs = (XYZZu*)(base + o_hs);
-    hipStream_t a1 = G > 1 ? c->aux1 : s, a2 = G > 1 ? c->aux2 : s;
-    hipEvent_t* ev = c->aux_events.data();
+    L->bin_shift = 0;
+    while (((n / p.NB) >> L->bin_shift) > 100) L->bin_shift++;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t E = L->E;
+    const uint32_t nb = L->n_buckets;
+    L->o_keys0 = carve(E * 4); L->o_keys1 = carve(E * 4); L->o_vals0 = carve(E * 4); L->o_vals1 = carve(E * 4);
+    L->o_cub = carve(L->cub_bytes);
+    L->o_start = carve(((size_t)nb + 2) * 4);
+    L->o_end = carve(((size_t)nb + 2) * 4);  // directly after start: one memset clears both
+    L->o_counts = carve((size_t)nb * 4);
+    L->o_perm = carve((size_t)nb * 4);
+    L->o_hist = carve(512 * 4);
+    L->o_buckets = carve((size_t)nb * sizeof(XYZZu));
+    L->o_acc = carve((size_t)p.W * L->m1 * sizeof(XYZZu));
+    L->o_run = carve((size_t)p.W * L->m1 * sizeof(XYZZu));
+    L->o_wsum = carve((size_t)p.W * sizeof(XYZZ));
+    L->o_T = carve((size_t)p.W * (L->D + 1) * 32 * sizeof(XYZZu));
+    L->o_hcnt = carve(16);
+    L->o_hb = carve(L->max_heavy * sizeof(HeavyBucket));
+    L->o_hc = carve(L->max_chunks * sizeof(HeavyChunk));
+    L->o_hs = carve(L->max_chunks * sizeof(XYZZu));
+    L->total = off;
+    return 0;
+}
 
-    rc = c->ws_acquire(s);
-    if (rc) return rc;
-    int t_all = c->timer_begin("msm_total", s);
+// stage A (memory-bound): digits, radix sort, bucket bounds, size order
+static int msm_stage_a(Ctx* c, const MsmLayout& L, char* base, const Fe* d_scalars, hipStream_t s) {
+    const MsmPlan& p = L.p;
+    const size_t n = L.n;
+    uint32_t *keys0 = (uint32_t*)(base + L.o_keys0), *keys1 = (uint32_t*)(base + L.o_keys1);
+    uint32_t *vals0 = (uint32_t*)(base + L.o_vals0), *vals1 = (uint32_t*)(base + L.o_vals1);
+    uint32_t *start = (uint32_t*)(base + L.o_start), *endp = (uint32_t*)(base + L.o_end);
+    uint32_t *counts = (uint32_t*)(base + L.o_counts), *perm = (uint32_t*)(base + L.o_perm), *hist = (uint32_t*)(base + L.o_hist);
     int t0 = c->timer_begin("msm_digits", s);
-    H2_CHECK(hipMemsetAsync(hcnt, 0, 16 * G, s));
-    H2_CHECK(hipMemsetAsync(start, 0, o_counts - o_start, s));  // start[] and end[]
-    H2_CHECK(hipMemsetAsync(hist, 0, (size_t)G * 512 * 4, s));
+    H2_CHECK(hipMemsetAsync(base + L.o_hcnt, 0, 16, s));
+    H2_CHECK(hipMemsetAsync(start, 0, L.o_counts - L.o_start, s));  // start[] and end[]
+    H2_CHECK(hipMemsetAsync(hist, 0, 512 * 4, s));
     hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, d_scalars, (uint32_t)n, p.c, p.W, p.NB, keys0, vals0);
     H2_CHECK(hipGetLastError());
     c->timer_end(t0, s);
-    if (G > 1) {
+    int t1 = c->timer_begin("msm_sort", s);
+    if (L.per_window_sort) {
+        for (uint32_t w = 0; w < p.W; w++)
+            H2_CHECK(hipcub::DeviceRadixSort::SortPairs(base + L.o_cub, const_cast<size_t&>(L.cub_bytes), keys0 + (size_t)w * n, keys1 + (size_t)w * n,
+                                                        vals0 + (size_t)w * n, vals1 + (size_t)w * n, (int)n, 0, L.end_bit, s));
+    } else {
+        H2_CHECK(hipcub::DeviceRadixSort::SortPairs(base + L.o_cub, const_cast<size_t&>(L.cub_bytes), keys0, keys1, vals0, vals1, (int)L.E, 0, L.end_bit, s));
+    }
+    {
+        size_t blocks = (L.E + 255) / 256;
+        uint32_t grid = (uint32_t)(blocks < (size_t)c->sm_count * 16 ? blocks : (size_t)c->sm_count * 16);
+        hipLaunchKernelGGL(msm_bounds_kernel, dim3(grid), dim3(256), 0, s, keys1, (size_t)0, L.E, p.c, start, endp);
+        H2_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(msm_bucket_hist_kernel, dim3((L.n_buckets + 255) / 256), dim3(256), 0, s, start, endp, 0u, L.n_buckets, L.bin_shift, counts, hist);
+    H2_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(msm_bucket_scatter_kernel, dim3((L.n_buckets + 255) / 256), dim3(256), 0, s, counts, 0u, L.n_buckets, L.bin_shift, hist, perm);
+    H2_CHECK(hipGetLastError());
+    c->timer_end(t1, s);
+    return 0;
+}
+
+// stage B (VALU-bound): bucket accumulation, plus the chunked path for over-full buckets
+static int msm_stage_b(Ctx* c, const MsmLayout& L, char* base, const Affine* d_bases, hipStream_t s) {
+    const MsmPlan& p = L.p;
+    uint32_t* vals1 = (uint32_t*)(base + L.o_vals1);
+    uint32_t *start = (uint32_t*)(base + L.o_start), *counts = (uint32_t*)(base + L.o_counts), *perm = (uint32_t*)(base + L.o_perm);
+    XYZZu* buckets = (XYZZu*)(base + L.o_buckets);
+    uint32_t* hcnt = (uint32_t*)(base + L.o_hcnt);
+    HeavyBucket* hb = (HeavyBucket*)(base + L.o_hb);
+    HeavyChunk* hc = (HeavyChunk*)(base + L.o_hc);
+    XYZZu* hs = (XYZZu*)(base + L.o_hs);
+    int t2 = c->timer_begin("msm_accum", s);
+    hipLaunchKernelGGL(msm_accum_kernel, dim3((L.n_buckets + 255) / 256), dim3(256), 0, s, d_bases, vals1, start, counts, perm,
+                       L.n_buckets, p.heavy_t, p.chunk, buckets, hcnt, hb, hc);
+    H2_CHECK(hipGetLastError());
+    c->timer_end(t2, s);
+    int t3 = c->timer_begin("msm_heavy", s);
+    uint32_t hgrid = (uint32_t)(L.max_chunks < (size_t)c->sm_count * 4 ? L.max_chunks : (size_t)c->sm_count * 4);
+    hipLaunchKernelGGL(msm_heavy_chunk_kernel, dim3(hgrid), dim3(256), 0, s, d_bases, vals1, hcnt, hc, hs);
+    H2_CHECK(hipGetLastError());
+    uint32_t fgrid = (uint32_t)(L.max_heavy < (size_t)c->sm_count ? L.max_heavy : (size_t)c->sm_count);
+    hipLaunchKernelGGL(msm_heavy_final_kernel, dim3(fgrid), dim3(256), 0, s, hcnt, hb, hs, buckets);
+    H2_CHECK(hipGetLastError());
+    c->timer_end(t3, s);
+    return 0;
+}
+
+// stage C (latency-bound): bucket reduction to W window sums, copied to h_ws (host)
+static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_ws, hipStream_t s) {
+    const MsmPlan& p = L.p;
+    XYZZu* buckets = (XYZZu*)(base + L.o_buckets);
+    XYZZu *accs = (XYZZu*)(base + L.o_acc), *runs = (XYZZu*)(base + L.o_run), *Tsum = (XYZZu*)(base + L.o_T);
+    XYZZ* wsum = (XYZZ*)(base + L.o_wsum);
+    int t4 = c->timer_begin("msm_reduce", s);
+    uint32_t n_seg = p.W * L.m1;
+    hipLaunchKernelGGL(msm_reduce1_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, s, buckets, n_seg, p.log_s1, accs, runs);
+    H2_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(msm_reduce2_kernel, dim3(p.W * (L.D + 1) * 32), dim3(64), 0, s, accs, runs, L.m1, L.dplan, Tsum);
+    H2_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(msm_reduce3_kernel, dim3(p.W), dim3(256), 0, s, Tsum, L.dplan, p.log_s1, wsum);
+    H2_CHECK(hipGetLastError());
+    c->timer_end(t4, s);
+    H2_CHECK(hipMemcpyAsync(h_ws, wsum, (size_t)p.W * sizeof(XYZZ), hipMemcpyDeviceToHost, s));
+    return 0;
+}
+
+// `count` independent MSMs of n <= 2^26 pairs each over the same bases (ParamsKZG::commit_lagrange for the
+// advice columns of one proof, plonk/prover.rs:361-365).  count == 1 runs the three stages back to back on the
+// caller's stream.  count > 1 pipelines whole MSMs over three streams with three workspace slots:
+//   aux1:  A(0) | A(1) | A(2) | ...            digits + sort + bounds      (memory-bound)
+//   s   :       | B(0) | B(1) | ...            accumulate                  (VALU-bound)
+//   aux2:              | C(0) | C(1) | ...     reduce + copy-out           (latency-bound, few waves)
+// so that every accumulate launch is full-size while the sort of the next MSM and the reduction of the previous
+// one run underneath it.
+// scalars_on_host: d_scalars[j] are host pointers, uploaded into three device slots ahead of stage A.
+static int msm_batch_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, const Affine* d_bases, size_t n, size_t count, XYZZ* h_out,
+                           hipStream_t s) {
+    MsmLayout L;
+    int rc = msm_layout(n, s, &L);
+    if (rc) return rc;
+    const size_t n_slots = count < 3 ? count : 3;
+    for (size_t k = 0; k < n_slots; k++) {
+        rc = c->msm_slot[k].ensure(L.total);
+        if (rc) return rc;
+        if (scalars_on_host) {
+            rc = c->msm_scalars[k].ensure(n * sizeof(Fe));
+            if (rc) return rc;
+        }
+    }
+    auto scalars_for = [&](size_t j, hipStream_t st, const Fe** out) -> int {
+        if (!scalars_on_host) {
+            *out = d_scalars[j];
+            return 0;
+        }
+        Fe* dst = (Fe*)c->msm_scalars[j % 3].p;  // stage A(j-3) read this slot earlier on the same stream
+        H2_CHECK(hipMemcpyAsync(dst, d_scalars[j], n * sizeof(Fe), hipMemcpyHostToDevice, st));
+        *out = dst;
+        return 0;
+    };
+    rc = c->host_ws.ensure(count * L.p.W * sizeof(XYZZ));
+    if (rc) return rc;
+    XYZZ* h_ws = (XYZZ*)c->host_ws.p;
+    rc = c->ws_acquire(s);
+    if (rc) return rc;
+    int t_all = c->timer_begin("msm_total", s);
+    if (count == 1) {
+        char* base = (char*)c->msm_slot[0].p;
+        const Fe* sc;
+        if ((rc = scalars_for(0, s, &sc))) return rc;
+        if ((rc = msm_stage_a(c, L, base, sc, s))) return rc;
+        if ((rc = msm_stage_b(c, L, base, d_bases, s))) return rc;
+        if ((rc = msm_stage_c(c, L, base, h_ws, s))) return rc;
+    } else {
+        // Three internal streams.  A full-size accumulate holds every wave slot for ~0.65 ms at a time, so the other
+        // stages only partly overlap with it (trace: profiles/): measured gain 17 % at 2^20, 37 % at 2^17.  Reserving
+        // CUs for stages A/C with CU-masked streams (h2hip_debug_set_reserved_cus) was slower for every split tried.
+        rc = c->ensure_aux(3 * count + 2);
+        if (rc) return rc;
+        hipStream_t a1 = c->aux1, a2 = c->aux2, sb = c->aux_b;
+        hipEvent_t* ev = c->aux_events.data();  // [0] start, [1+3j] A(j) done, [2+3j] B(j) done, [3+3j] C(j) done
         H2_CHECK(hipEventRecord(ev[0], s));
         H2_CHECK(hipStreamWaitEvent(a1, ev[0], 0));
-    }
-
-    for (uint32_t g = 0; g < G; g++) {
-        const uint32_t w0 = g * wpg, w1 = (w0 + wpg < p.W) ? w0 + wpg : p.W;
-        if (w0 >= w1) break;
-        const uint32_t Wg = w1 - w0, gb0 = w0 * p.NB, nbg = Wg * p.NB;
-        const size_t e0 = (size_t)w0 * n, Eg = (size_t)Wg * n;
-
-        // ---- aux1: sort + bucket bounds + size order of this group
-        int t1 = c->timer_begin("msm_sort", a1);
-        if (per_window_sort) {
-            for (uint32_t w = w0; w < w1; w++)
-                H2_CHECK(hipcub::DeviceRadixSort::SortPairs(base + o_cub, cub_bytes, keys0 + (size_t)w * n, keys1 + (size_t)w * n,
-                                                            vals0 + (size_t)w * n, vals1 + (size_t)w * n, (int)n, 0, end_bit, a1));
-        } else {
-            H2_CHECK(hipcub::DeviceRadixSort::SortPairs(base + o_cub, cub_bytes, keys0 + e0, keys1 + e0, vals0 + e0, vals1 + e0, (int)Eg, 0, end_bit, a1));
+        H2_CHECK(hipStreamWaitEvent(a2, ev[0], 0));
+        H2_CHECK(hipStreamWaitEvent(sb, ev[0], 0));
+        for (size_t j = 0; j < count; j++) {
+            char* base = (char*)c->msm_slot[j % 3].p;
+            if (j >= 3) H2_CHECK(hipStreamWaitEvent(a1, ev[3 + 3 * (j - 3)], 0));  // slot reuse: C(j-3) has drained it
+            const Fe* sc;
+            if ((rc = scalars_for(j, a1, &sc))) return rc;
+            if ((rc = msm_stage_a(c, L, base, sc, a1))) return rc;
+            H2_CHECK(hipEventRecord(ev[1 + 3 * j], a1));
+            H2_CHECK(hipStreamWaitEvent(sb, ev[1 + 3 * j], 0));
+            if ((rc = msm_stage_b(c, L, base, d_bases, sb))) return rc;
+            H2_CHECK(hipEventRecord(ev[2 + 3 * j], sb));
+            H2_CHECK(hipStreamWaitEvent(a2, ev[2 + 3 * j], 0));
+            if ((rc = msm_stage_c(c, L, base, h_ws + j * L.p.W, a2))) return rc;
+            H2_CHECK(hipEventRecord(ev[3 + 3 * j], a2));
         }
-        {
-            size_t blocks = (Eg + 255) / 256;
-            uint32_t grid = (uint32_t)(blocks < (size_t)c->sm_count * 16 ? blocks : (size_t)c->sm_count * 16);
-            hipLaunchKernelGGL(msm_bounds_kernel, dim3(grid), dim3(256), 0, a1, keys1, e0, e0 + Eg, p.c, start, endp);
-            H2_CHECK(hipGetLastError());
-        }
-        hipLaunchKernelGGL(msm_bucket_hist_kernel, dim3((nbg + 255) / 256), dim3(256), 0, a1, start, endp, gb0, nbg, bin_shift, counts, hist + 512 * g);
-        H2_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(msm_bucket_scatter_kernel, dim3((nbg + 255) / 256), dim3(256), 0, a1, counts, gb0, nbg, bin_shift, hist + 512 * g, perm + gb0);
-        H2_CHECK(hipGetLastError());
-        c->timer_end(t1, a1);
-        if (G > 1) {
-            H2_CHECK(hipEventRecord(ev[1 + g], a1));
-            H2_CHECK(hipStreamWaitEvent(s, ev[1 + g], 0));
-        }
-
-        // ---- s: accumulate this group's buckets (+ over-full buckets)
-        int t2 = c->timer_begin("msm_accum", s);
-        hipLaunchKernelGGL(msm_accum_kernel, dim3((nbg + 255) / 256), dim3(256), 0, s, d_bases, vals1, start, counts, perm + gb0, nbg, p.heavy_t, p.chunk,
-                           buckets, hcnt + 4 * g, hb + g * max_heavy, hc + g * max_chunks);
-        H2_CHECK(hipGetLastError());
-        c->timer_end(t2, s);
-        int t3 = c->timer_begin("msm_heavy", s);
-        uint32_t hgrid = (uint32_t)(max_chunks < (size_t)c->sm_count * 4 ? max_chunks : (size_t)c->sm_count * 4);
-        hipLaunchKernelGGL(msm_heavy_chunk_kernel, dim3(hgrid), dim3(256), 0, s, d_bases, vals1, hcnt + 4 * g, hc + g * max_chunks, hs + g * max_chunks);
-        H2_CHECK(hipGetLastError());
-        uint32_t fgrid = (uint32_t)(max_heavy < (size_t)c->sm_count ? max_heavy : (size_t)c->sm_count);
-        hipLaunchKernelGGL(msm_heavy_final_kernel, dim3(fgrid), dim3(256), 0, s, hcnt + 4 * g, hb + g * max_heavy, hs + g * max_chunks, buckets);
-        H2_CHECK(hipGetLastError());
-        c->timer_end(t3, s);
-        if (G > 1) {
-            H2_CHECK(hipEventRecord(ev[1 + G + g], s));
-            H2_CHECK(hipStreamWaitEvent(a2, ev[1 + G + g], 0));
-        }
-
-        // ---- aux2: reduce this group's windows
-        int t4 = c->timer_begin("msm_reduce", a2);
-        uint32_t n_seg = Wg * m1;
-        hipLaunchKernelGGL(msm_reduce1_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, a2, buckets + gb0, n_seg, p.log_s1, accs + (size_t)w0 * m1,
-                           runs + (size_t)w0 * m1);
-        H2_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(msm_reduce2_kernel, dim3(Wg * (D + 1) * 32), dim3(64), 0, a2, accs + (size_t)w0 * m1, runs + (size_t)w0 * m1, m1, dplan,
-                           Tsum + (size_t)w0 * (D + 1) * 32);
-        H2_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(msm_reduce3_kernel, dim3(Wg), dim3(256), 0, a2, Tsum + (size_t)w0 * (D + 1) * 32, dplan, p.log_s1, wsum + w0);
-        H2_CHECK(hipGetLastError());
-        c->timer_end(t4, a2);
-    }
-    if (G > 1) {
-        H2_CHECK(hipEventRecord(ev[1 + 2 * G], a2));
-        H2_CHECK(hipStreamWaitEvent(s, ev[1 + 2 * G], 0));
+        H2_CHECK(hipStreamWaitEvent(s, ev[3 + 3 * (count - 1)], 0));  // C stages are in order on aux2
     }
     c->timer_end(t_all, s);
-
-    XYZZ h_ws[MSM_MAX_WINDOWS * 2];
-    H2_CHECK(hipMemcpyAsync(h_ws, wsum, (size_t)p.W * sizeof(XYZZ), hipMemcpyDeviceToHost, s));
     H2_CHECK(hipStreamSynchronize(s));
-    *h_out = combine_windows(h_ws, p);
+    for (size_t j = 0; j < count; j++) h_out[j] = combine_windows(h_ws + j * L.p.W, L.p);
     return c->ws_release(s);
+}
+
+// count MSMs over the same bases for device-resident inputs; results (XYZZ) to host memory.
+int msm_batch_device(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, const Affine* d_bases, size_t n, size_t count, XYZZ* h_out,
+                     hipStream_t s) {
+    for (size_t j = 0; j < count; j++) h_out[j] = xyzz_identity();
+    if (n == 0 || count == 0) return 0;
+    // the pair index lives in 31 bits and the sort counts in int: split very large inputs
+    const size_t max_chunk = (size_t)1 << 26;
+    std::vector<const Fe*> ptrs(count);
+    std::vector<XYZZ> part(count);
+    for (size_t o = 0; o < n; o += max_chunk) {
+        size_t m = n - o < max_chunk ? n - o : max_chunk;
+        for (size_t j = 0; j < count; j++) ptrs[j] = d_scalars[j] + o;
+        int rc = msm_batch_chunk(c, ptrs.data(), scalars_on_host, d_bases + o, m, count, part.data(), s);
+        if (rc) return rc;
+        for (size_t j = 0; j < count; j++) xyzz_add(h_out[j], part[j]);
+    }
+    return 0;
 }
 
 // Sum of coeffs[i]*bases[i] for device-resident inputs; result (XYZZ) to host memory.
 int msm_device(Ctx* c, const Fe* d_scalars, const Affine* d_bases, size_t n, XYZZ* h_out, hipStream_t s) {
-    *h_out = xyzz_identity();
-    if (n == 0) return 0;
-    // the pair index lives in 31 bits and the sort counts in int: split very large inputs
-    const size_t max_chunk = (size_t)1 << 26;
-    for (size_t o = 0; o < n; o += max_chunk) {
-        size_t m = n - o < max_chunk ? n - o : max_chunk;
-        XYZZ part;
-        int rc = msm_device_chunk(c, d_scalars + o, d_bases + o, m, &part, s);
-        if (rc) return rc;
-        xyzz_add(*h_out, part);
-    }
-    return 0;
+    return msm_batch_device(c, &d_scalars, false, d_bases, n, 1, h_out, s);
 }
 
 }  // namespace h2

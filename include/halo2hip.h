@@ -71,6 +71,14 @@ int h2hip_bases_unpin(const uint64_t* bases_xy);
  * the call returns after the stream is synchronised and the result is in host memory. */
 int h2hip_msm_bn254_device(const void* d_scalars, const void* d_bases_xy, size_t n, uint64_t out_xyz[12], void* stream);
 
+/* `count` independent MSMs of n pairs each over the SAME bases: out_xyz[12*j..] = sum_i scalars[j][i] * bases[i].
+ * This is what create_proof does when it commits its columns back to back (plonk/prover.rs:361-365:
+ * `params.commit_lagrange(poly, blind)` for every advice polynomial; lookup/prover.rs:127-132, :291;
+ * vanishing/prover.rs:104).  Results equal `count` separate h2hip_msm_bn254 calls; the engine pipelines whole
+ * MSMs over three streams (sort of j+1 and reduction of j-1 under the accumulation of j). */
+int h2hip_msm_bn254_batch(const uint64_t* const* scalars, const uint64_t* bases_xy, size_t n, size_t count, uint64_t* out_xyz);
+int h2hip_msm_bn254_batch_device(const void* const* d_scalars, const void* d_bases_xy, size_t n, size_t count, uint64_t* out_xyz, void* stream);
+
 /* Left fold of k Jacobian partial sums from the identity -- the fold at arithmetic.rs:153.
  * Multi-GPU MSM: each rank computes its shard's partial with h2hip_msm_bn254[_device], the
  * 96-byte partials are all-gathered (RCCL, bytes), and every rank folds them with this. */
@@ -120,8 +128,6 @@ int h2hip_gen_points_device(uint64_t seed, uint64_t start, size_t n, void* d_out
 
 /* MSM window width in bits (2..22); 0 restores the size-based default */
 int h2hip_set_msm_window(uint32_t c);
-/* number of window groups the MSM pipelines over its three streams (1 = no overlap); 0 = size-based default */
-int h2hip_set_msm_groups(uint32_t g);
 /* window width the engine would use for n pairs */
 uint32_t h2hip_get_msm_window(size_t n);
 /* Per-stage HIP-event timers recorded on the stream each kernel group is launched on.

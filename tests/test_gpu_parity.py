@@ -349,3 +349,39 @@ def test_ntt_large_roundtrip(h2, oracle, k):
     torch.cuda.synchronize()
     assert torch.equal(da, ref)
     assert torch.equal(da[:4096], keep)
+
+
+@pytest.mark.parametrize("count", [1, 2, 3, 4, 7])
+def test_msm_batch_matches_single_calls(h2, oracle, count):
+    """h2hip_msm_bn254_batch: the back-to-back commits of plonk/prover.rs:361-365 pipelined over three
+    streams and three workspace slots must equal `count` separate best_multiexp calls (and the oracle)."""
+    n = (1 << 13) + 5
+    bs = oracle.gen_points(900, n, num_threads=NT)
+    cols = [(_prover_like(oracle, n, 910 + j) if j % 2 else oracle.gen_scalars(910 + j, n, num_threads=NT)) for j in range(count)]
+    want = [oracle.g1_to_affine(oracle.best_multiexp(c, bs, NT)) for c in cols]
+    got = h2.best_multiexp_batch(cols, bs)
+    for j in range(count):
+        assert np.array_equal(aff(h2, got[j]), want[j]), j
+    # device-resident form, pinned-bases form
+    import torch
+    dcols = [torch.from_numpy(c.view(np.int64)).cuda() for c in cols]
+    dbs = torch.from_numpy(bs.view(np.int64)).cuda()
+    got = h2.msm_batch_device(dcols, dbs)
+    for j in range(count):
+        assert np.array_equal(aff(h2, got[j]), want[j]), j
+    h2.bases_pin(bs)
+    try:
+        got = h2.best_multiexp_batch(cols, bs)
+    finally:
+        h2.bases_unpin(bs)
+    for j in range(count):
+        assert np.array_equal(aff(h2, got[j]), want[j]), j
+
+
+def test_msm_batch_2p20_pipelined(h2, oracle):
+    n = 1 << 20
+    dp = h2.gen_points_device(0x5EED0002, n)
+    dcols = [h2.gen_scalars_device(0x5EED0001, n, start=j * n) for j in range(5)]
+    got = h2.msm_batch_device(dcols, dp)
+    for j in range(5):
+        assert np.array_equal(aff(h2, got[j]), aff(h2, h2.msm_device(dcols[j], dp))), j
