@@ -11,6 +11,7 @@ namespace h2 {
 int gen_scalars_device(uint64_t seed, uint64_t start, size_t n, Fe* d_out, hipStream_t s);
 int gen_points_device(uint64_t seed, uint64_t start, size_t n, Affine* d_out, hipStream_t s);
 void msm_set_window(uint32_t c);
+void ntt_set_smax(uint32_t v);
 void msm_set_reserved_cus(uint32_t k);
 uint32_t msm_get_reserved_cus();
 uint32_t msm_get_window(size_t n);
@@ -631,6 +632,11 @@ int h2hip_set_msm_window(uint32_t c) {
 }
 
 uint32_t h2hip_get_msm_window(size_t n) { return msm_get_window(n); }
+
+int h2hip_debug_set_ntt_smax(uint32_t v) {
+    ntt_set_smax(v);
+    return 0;
+}
 
 // undocumented tuning knob (not in the public header): CUs reserved for the sort / reduce stages of a batch
 int h2hip_debug_set_reserved_cus(uint32_t k) {

@@ -51,16 +51,52 @@ __device__ __forceinline__ Fu tw_pow(const NttPass& p, uint64_t e) {
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t k, uint32_t s) { return __brev(k) >> (32 - s); }
 
-// R-point DFT on J columns held in LDS as x[col*R + bitrev(r)] on entry, x[col*R + k] on exit
-// (decimation in time).  Stage 1 has unit twiddles; every later stage multiplies (also by w^0 = 1,
-// which keeps |value| growing by at most ~1.3 r per stage instead of doubling); limbs are
-// re-normalised after every even stage, which keeps every fu_mul operand below 2^30.
+// kernel-argument constants are picked with selects: a dynamic index would send the whole array to scratch
+__device__ __forceinline__ Fu pick3(const Fu c[3], uint32_t m) {
+    Fu r = c[0];
+    if (m == 1) r = c[1];
+    if (m == 2) r = c[2];
+    return r;
+}
+
+// R-point DFT on J columns held in LDS as x[col*R + bitrev(r)] on entry, x[col*R + k] on exit (decimation in
+// time).  Two butterfly stages per LDS round trip: a lane takes the four elements base + {0, h, 2h, 3h}, runs
+// the stage of half-size h on (x0,x1), (x2,x3) and the stage of half-size 2h on (y0,y2), (y1,y3) in registers.
+// Every stage multiplies by its twiddle, w^0 = 1 included (keeps |value| growing by at most ~1.3 r per stage
+// instead of doubling), except stage 0 whose twiddles are all 1 and whose inputs are fresh; limbs are
+// re-normalised after each stage pair, which keeps every fu_mul operand below 2^30.  An odd s ends with one
+// single stage whose loose outputs the canonicalising store accepts.
 __device__ __forceinline__ void dft_lds(Fu* x, const Fu* wtab, uint32_t s, uint32_t log_j) {
     const uint32_t R = 1u << s;
-    const uint32_t nbf = (R << log_j) >> 1;
-    for (uint32_t log_h = 0; log_h < s; log_h++) {
+    uint32_t log_h = 0;
+    const uint32_t nq = (R << log_j) >> 2;
+    for (; log_h + 2 <= s; log_h += 2) {
         const uint32_t h = 1u << log_h;
-        const bool norm = (log_h & 1) != 0;
+        for (uint32_t q = threadIdx.x; q < nq; q += NTT_THREADS) {
+            uint32_t col = q >> (s - 2);
+            uint32_t i = q & ((R >> 2) - 1);
+            uint32_t off = i & (h - 1);
+            uint32_t blk = i >> log_h;
+            uint32_t base = (col << s) + (blk << (log_h + 2)) + off;
+            Fu x0 = x[base], x1 = x[base + h], x2 = x[base + 2 * h], x3 = x[base + 3 * h];
+            if (log_h) {
+                Fu wa = wtab[off << (s - 1 - log_h)];
+                x1 = fu_mul<FrU>(x1, wa);
+                x3 = fu_mul<FrU>(x3, wa);
+            }
+            Fu y0 = fu_add(x0, x1), y1 = fu_sub(x0, x1), y2 = fu_add(x2, x3), y3 = fu_sub(x2, x3);
+            Fu u2 = fu_mul<FrU>(y2, wtab[off << (s - 2 - log_h)]);
+            Fu u3 = fu_mul<FrU>(y3, wtab[(off + h) << (s - 2 - log_h)]);
+            x[base] = fu_norm(fu_add(y0, u2));
+            x[base + 2 * h] = fu_norm(fu_sub(y0, u2));
+            x[base + h] = fu_norm(fu_add(y1, u3));
+            x[base + 3 * h] = fu_norm(fu_sub(y1, u3));
+        }
+        __syncthreads();
+    }
+    if (log_h < s) {  // odd s: last stage on its own
+        const uint32_t h = 1u << log_h;
+        const uint32_t nbf = (R << log_j) >> 1;
         for (uint32_t bf = threadIdx.x; bf < nbf; bf += NTT_THREADS) {
             uint32_t col = bf >> (s - 1);
             uint32_t i = bf & ((R >> 1) - 1);
@@ -70,13 +106,8 @@ __device__ __forceinline__ void dft_lds(Fu* x, const Fu* wtab, uint32_t s, uint3
             uint32_t i1 = i0 + h;
             Fu a = x[i0], t = x[i1];
             if (log_h) t = fu_mul<FrU>(t, wtab[off << (s - 1 - log_h)]);
-            Fu u = fu_add(a, t), v = fu_sub(a, t);
-            if (norm) {
-                u = fu_norm(u);
-                v = fu_norm(v);
-            }
-            x[i0] = u;
-            x[i1] = v;
+            x[i0] = fu_add(a, t);
+            x[i1] = fu_sub(a, t);
         }
         __syncthreads();
     }
@@ -88,7 +119,7 @@ __device__ __forceinline__ Fu ntt_load(const NttPass& p, uint64_t gi) {
         Fu v = fu_slice(p.src[gi]);
         if (p.in_scale) {
             uint32_t m = (uint32_t)(gi % 3);
-            if (m) v = fu_mul<FrU>(v, p.in3[m]);
+            if (m) v = fu_mul<FrU>(v, pick3(p.in3, m));
         }
         return v;
     }
@@ -144,7 +175,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_final_kernel(NttPass p) {
     for (uint32_t idx = threadIdx.x; idx < (R << p.log_j); idx += NTT_THREADS) {
         uint32_t k = idx >> p.log_j, jj = idx & (J - 1);
         uint64_t oi = ((uint64_t)k << log_nb) + (g << p.log_j) + jj;
-        Fu c = p.out_scale ? p.out3[oi % 3] : one_i;
+        Fu c = p.out_scale ? pick3(p.out3, (uint32_t)(oi % 3)) : one_i;
         p.dst[oi] = fu_mul_canon<FrU>(x[(jj << p.s) + k], c);
     }
 }
@@ -205,13 +236,19 @@ static int get_twiddles(Ctx* c, const Fe& omega, uint32_t log_n, hipStream_t s, 
     return 0;
 }
 
-// pass radices: one pass up to 2^10, otherwise ceil(log_n / 8) passes of near-equal radix
+static uint32_t g_ntt_smax = 8;
+void ntt_set_smax(uint32_t v) { g_ntt_smax = v < 4 ? 4 : (v > 10 ? 10 : v); }
+
+// pass radices: one pass up to 2^10, otherwise ceil(log_n / smax) passes of near-equal radix
 static int plan_passes(uint32_t log_n, uint32_t s_out[4]) {
     if (log_n <= 10) {
         s_out[0] = log_n;
         return 1;
     }
-    int P = (int)((log_n + 7) / 8);
+    // measured (tools/ntt_sweep.py): 256-point tiles are best up to 2^24; beyond, 512-point tiles save a whole pass
+    const uint32_t smax = (g_ntt_smax == 8 && log_n > 24) ? 9 : g_ntt_smax;
+    int P = (int)((log_n + smax - 1) / smax);
+    if (P > 4) P = 4;
     uint32_t base = log_n / P, rem = log_n % P;
     for (int t = 0; t < P; t++) s_out[t] = base + ((uint32_t)t < rem ? 1 : 0);
     return P;
@@ -271,7 +308,8 @@ int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttSca
             p.src = (P == 1) ? d_data : ws;
             p.dst = d_data;
             uint32_t log_nb = log_n - p.s;
-            p.log_j = log_nb < 2 ? log_nb : 2;
+            const uint32_t want_j = p.s <= 8 ? 2 : 1;  // 4 columns (128 B rows) up to 256-point tiles, 2 beyond: LDS
+            p.log_j = log_nb < want_j ? log_nb : want_j;
             p.n_prev = (uint32_t)(P - 1);
             for (int q = 0; q < P - 1; q++) p.prev_s[q] = S[q];
         } else {
@@ -279,7 +317,8 @@ int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttSca
             p.src = d_data;
             p.dst = to_ws ? ws : d_data;
             uint32_t log_l = log_m - p.s;
-            p.log_j = log_l < 2 ? log_l : 2;
+            const uint32_t want_j = p.s <= 8 ? 2 : 1;
+            p.log_j = log_l < want_j ? log_l : want_j;
         }
         size_t lds = (((size_t)1 << (p.s + p.log_j)) + ((size_t)1 << p.s) / 2 + 1) * sizeof(Fu);
         uint64_t grid = 1ull << (log_n - p.s - p.log_j);
