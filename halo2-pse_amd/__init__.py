@@ -201,6 +201,16 @@ class EvaluationDomain:
         return a[: self.n * self.quotient_poly_degree]
 
 
+    def divide_by_vanishing_poly(self, a, t_evaluations):
+        """poly/domain.rs:307-326"""
+        a = _u64(a, 4).copy()
+        t = _u64(t_evaluations, 4)
+        assert a.shape[0] == self.extended_len()
+        _check(lib().h2hip_divide_by_vanishing_poly_bn254_fr(_p(a), ctypes.c_uint32(self.extended_k), _p(t), ctypes.c_uint32(t.shape[0])),
+               "h2hip_divide_by_vanishing_poly_bn254_fr")
+        return a
+
+
 # ------------------------------------------------------------------ poly/kzg/commitment.rs
 class ParamsKZG:
     """poly::kzg::commitment::ParamsKZG<Bn256> (poly/kzg/commitment.rs:22-30): g and g_lagrange

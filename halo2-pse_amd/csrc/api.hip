@@ -602,6 +602,39 @@ int h2hip_extended_to_coeff_bn254_fr(uint64_t* a, uint32_t extended_k, const uin
     return ntt_host(a, fe_from_u64x4(extended_omega_inv), extended_k, &sc, nullptr, 0);
 }
 
+int h2hip_divide_by_vanishing_poly_bn254_fr_device(void* d_a, uint32_t extended_k, const uint64_t* t_evaluations, uint32_t t_len, void* stream) {
+    if (!d_a || !t_evaluations || extended_k > 28 || t_len == 0) {
+        set_error("divide_by_vanishing_poly: bad argument");
+        return H2HIP_EINVAL;
+    }
+    for (uint32_t i = 0; i < t_len; i++)
+        if (check_fr(t_evaluations + 4 * i, "t_evaluations[i]")) return H2HIP_EINVAL;
+    Entry en;
+    if (en.rc) return en.rc;
+    return scale_periodic_device(en.c, (Fe*)d_a, 1ull << extended_k, (const Fe*)t_evaluations, t_len, (hipStream_t)stream);
+}
+
+int h2hip_divide_by_vanishing_poly_bn254_fr(uint64_t* a, uint32_t extended_k, const uint64_t* t_evaluations, uint32_t t_len) {
+    if (!a || !t_evaluations || extended_k > 28 || t_len == 0) {
+        set_error("divide_by_vanishing_poly: bad argument");
+        return H2HIP_EINVAL;
+    }
+    for (uint32_t i = 0; i < t_len; i++)
+        if (check_fr(t_evaluations + 4 * i, "t_evaluations[i]")) return H2HIP_EINVAL;
+    Entry en;
+    if (en.rc) return en.rc;
+    Ctx* c = en.c;
+    size_t bytes = sizeof(Fe) << extended_k;
+    int rc = c->ntt_io.ensure(bytes);
+    if (rc) return rc;
+    H2_CHECK(hipMemcpyAsync(c->ntt_io.p, a, bytes, hipMemcpyHostToDevice, c->stream));
+    rc = scale_periodic_device(c, (Fe*)c->ntt_io.p, 1ull << extended_k, (const Fe*)t_evaluations, t_len, c->stream);
+    if (rc) return rc;
+    H2_CHECK(hipMemcpyAsync(a, c->ntt_io.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    H2_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int h2hip_gen_scalars_device(uint64_t seed, uint64_t start, size_t n, void* d_out, void* stream) {
     if (n && !d_out) {
         set_error("gen_scalars: null output");

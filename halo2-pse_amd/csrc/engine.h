@@ -115,6 +115,8 @@ struct NttScale {
 };
 int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttScale* sc, hipStream_t s);
 
+int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const Fe* h_t, uint32_t t_len, hipStream_t s);
+
 // msm.hip
 int msm_device(Ctx* c, const Fe* d_scalars, const Affine* d_bases, size_t n, XYZZ* h_out, hipStream_t s);
 int msm_batch_device(Ctx* c, const Fe* const* scalars, bool scalars_on_host, const Affine* d_bases, size_t n, size_t count, XYZZ* h_out,

@@ -16,6 +16,8 @@
 // into the first load and the last store.
 #include <string.h>
 
+#include <vector>
+
 #include "engine.h"
 #include "fieldu.cuh"
 
@@ -234,6 +236,32 @@ static int get_twiddles(Ctx* c, const Fe& omega, uint32_t log_n, hipStream_t s, 
     c->twiddles[key] = t;
     *out = t;
     return 0;
+}
+
+// EvaluationDomain::divide_by_vanishing_poly (poly/domain.rs:307-326): a[i] *= t_evaluations[i % t_len]
+__global__ void __launch_bounds__(256) scale_periodic_kernel(Fe* a, uint64_t n, const Fu* t_i, uint32_t t_len) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        a[i] = fu_mul_canon<FrU>(fu_slice(a[i]), t_i[i % t_len]);
+}
+
+int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const Fe* h_t, uint32_t t_len, hipStream_t s) {
+    if (t_len == 0 || t_len > 4096) {
+        set_error("divide_by_vanishing_poly: t_len %u out of range", t_len);
+        return 1;
+    }
+    int rc = c->ws_acquire(s);
+    if (rc) return rc;
+    rc = c->misc.ensure((size_t)t_len * sizeof(Fu));
+    if (rc) return rc;
+    std::vector<Fu> t(t_len);
+    for (uint32_t i = 0; i < t_len; i++) t[i] = fu_i_from_fe(h_t[i]);
+    H2_CHECK(hipMemcpyAsync(c->misc.p, t.data(), (size_t)t_len * sizeof(Fu), hipMemcpyHostToDevice, s));
+    H2_CHECK(hipStreamSynchronize(s));  // t lives on this stack frame
+    uint64_t blocks = (n + 255) / 256;
+    uint32_t grid = (uint32_t)(blocks < (uint64_t)c->sm_count * 16 ? blocks : (uint64_t)c->sm_count * 16);
+    hipLaunchKernelGGL(scale_periodic_kernel, dim3(grid), dim3(256), 0, s, d_a, n, (const Fu*)c->misc.p, t_len);
+    H2_CHECK(hipGetLastError());
+    return c->ws_release(s);
 }
 
 static uint32_t g_ntt_smax = 8;

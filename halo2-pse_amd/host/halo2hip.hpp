@@ -191,10 +191,11 @@ class EvaluationDomain {
         return std::move(a.values);
     }
 
-    // divide_by_vanishing_poly (poly/domain.rs:307-326): pointwise on the host, as in the reference
+    // divide_by_vanishing_poly (poly/domain.rs:307-326)
     Polynomial<ExtendedLagrangeCoeff> divide_by_vanishing_poly(Polynomial<ExtendedLagrangeCoeff> a) const {
-        if (a.values.size() != extended_len()) throw std::logic_error("assertion failed: a.values.len() == self.extended_len()");
-        for (size_t i = 0; i < a.values.size(); i++) a.values[i] = a.values[i] * t_evaluations[i % t_evaluations.size()];
+        if (a.values.size() != extended_len()) throw std::logic_error("assertion failed: a.values.len() == self.extended_len()");  // :311
+        engine_check(h2hip_divide_by_vanishing_poly_bn254_fr(a.values[0].l, extended_k, t_evaluations[0].l, uint32_t(t_evaluations.size())),
+                     "divide_by_vanishing_poly");
         return a;
     }
 };

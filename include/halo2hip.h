@@ -119,6 +119,11 @@ int h2hip_extended_to_coeff_bn254_fr_device(void* d_a, uint32_t extended_k, cons
                                             const uint64_t extended_ifft_divisor[4], const uint64_t g_coset[4],
                                             const uint64_t g_coset_inv[4], void* stream);
 
+/* EvaluationDomain::divide_by_vanishing_poly (poly/domain.rs:307-326): a[i] *= t_evaluations[i % t_len] on the
+ * 2^extended_k coset evaluations, t_evaluations = the domain's inverted t(X) = X^n - 1 values (:84-124). */
+int h2hip_divide_by_vanishing_poly_bn254_fr(uint64_t* a, uint32_t extended_k, const uint64_t* t_evaluations, uint32_t t_len);
+int h2hip_divide_by_vanishing_poly_bn254_fr_device(void* d_a, uint32_t extended_k, const uint64_t* t_evaluations, uint32_t t_len, void* stream);
+
 /* ---- synthetic workload; same streams as oracle_gen_{scalars,points} ---- */
 
 int h2hip_gen_scalars_device(uint64_t seed, uint64_t start, size_t n, void* d_out, void* stream);

@@ -385,3 +385,30 @@ def test_msm_batch_2p20_pipelined(h2, oracle):
     got = h2.msm_batch_device(dcols, dp)
     for j in range(5):
         assert np.array_equal(aff(h2, got[j]), aff(h2, h2.msm_device(dcols[j], dp))), j
+
+
+@pytest.mark.parametrize("jk", [(4, 5), (3, 4), (4, 12), (2, 9)])
+def test_divide_by_vanishing_poly(h2, oracle, golden, jk):
+    j, k = jk
+    d, t_eval = oracle.domain_new(j, k)
+    dom = _domain(h2, d)
+    if (j, k) in ((4, 5), (3, 4)):
+        got = dom.divide_by_vanishing_poly(golden[f"ext_{j}_{k}_h_extended"], t_eval)
+        assert np.array_equal(got, golden[f"ext_{j}_{k}_h_divided"])
+    h = oracle.gen_scalars(777 + k, 1 << d.extended_k, num_threads=NT)
+    assert np.array_equal(dom.divide_by_vanishing_poly(h, t_eval), oracle.divide_by_vanishing_poly(d, t_eval, h))
+
+
+def test_lifecycle_and_edge_cases(h2, oracle):
+    # shutdown + lazy re-init; count = 0 batch; n = 0; null-free error reporting
+    sc = oracle.gen_scalars(1, 100)
+    bs = oracle.gen_points(2, 100)
+    want = oracle.g1_to_affine(oracle.best_multiexp(sc, bs, 2))
+    assert np.array_equal(aff(h2, h2.best_multiexp(sc, bs)), want)
+    h2.shutdown()
+    assert np.array_equal(aff(h2, h2.best_multiexp(sc, bs)), want)  # entry points re-initialise lazily
+    assert h2.best_multiexp_batch([], bs).shape == (0, 12)
+    z = h2.best_multiexp_batch([sc[:0], sc[:0]], bs[:0])
+    assert np.array_equal(aff(h2, z[0]), np.zeros(8, dtype=np.uint64)) and np.array_equal(aff(h2, z[1]), np.zeros(8, dtype=np.uint64))
+    assert "halo2hip" in h2.version()
+    assert h2.device_count() >= 1
