@@ -11,6 +11,7 @@ namespace h2 {
 int gen_scalars_device(uint64_t seed, uint64_t start, size_t n, Fe* d_out, hipStream_t s);
 int gen_points_device(uint64_t seed, uint64_t start, size_t n, Affine* d_out, hipStream_t s);
 void msm_set_window(uint32_t c);
+void msm_set_max_chunk(size_t m);
 void ntt_set_smax(uint32_t v);
 void msm_set_reserved_cus(uint32_t k);
 uint32_t msm_get_reserved_cus();
@@ -665,6 +666,12 @@ int h2hip_set_msm_window(uint32_t c) {
 }
 
 uint32_t h2hip_get_msm_window(size_t n) { return msm_get_window(n); }
+
+// test hook: split inputs above m pairs into consecutive chunks (default 2^26, the 31-bit pair-index limit)
+int h2hip_debug_set_msm_max_chunk(size_t m) {
+    msm_set_max_chunk(m);
+    return 0;
+}
 
 int h2hip_debug_set_ntt_smax(uint32_t v) {
     ntt_set_smax(v);

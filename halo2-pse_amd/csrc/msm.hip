@@ -311,6 +311,8 @@ __global__ void __launch_bounds__(256) msm_reduce3_kernel(const XYZZu* __restric
 }
 
 static uint32_t g_window_override = 0;
+static size_t g_max_chunk = (size_t)1 << 26;
+void msm_set_max_chunk(size_t m) { g_max_chunk = m ? m : ((size_t)1 << 26); }
 static uint32_t g_reserved_cus = 0;  // measured on MI355X: every partition (16..96 CUs) was slower than none
 void msm_set_reserved_cus(uint32_t k) { g_reserved_cus = k; }
 uint32_t msm_get_reserved_cus() { return g_reserved_cus; }
@@ -608,7 +610,7 @@ int msm_batch_device(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, c
     for (size_t j = 0; j < count; j++) h_out[j] = xyzz_identity();
     if (n == 0 || count == 0) return 0;
     // the pair index lives in 31 bits and the sort counts in int: split very large inputs
-    const size_t max_chunk = (size_t)1 << 26;
+    const size_t max_chunk = g_max_chunk;
     std::vector<const Fe*> ptrs(count);
     std::vector<XYZZ> part(count);
     for (size_t o = 0; o < n; o += max_chunk) {

@@ -412,3 +412,32 @@ def test_lifecycle_and_edge_cases(h2, oracle):
     assert np.array_equal(aff(h2, z[0]), np.zeros(8, dtype=np.uint64)) and np.array_equal(aff(h2, z[1]), np.zeros(8, dtype=np.uint64))
     assert "halo2hip" in h2.version()
     assert h2.device_count() >= 1
+
+
+def test_msm_chunked_inputs(h2, oracle):
+    """inputs above the 2^26-pair sort limit are split into consecutive chunks whose results are added; the
+    split is exercised here with the limit lowered to 1000 pairs (single and batched entry points)."""
+    import ctypes
+    n = 4321
+    sc = [oracle.gen_scalars(40 + j, n) for j in range(3)]
+    bs = oracle.gen_points(44, n, num_threads=NT)
+    want = [oracle.g1_to_affine(oracle.best_multiexp(s_, bs, NT)) for s_ in sc]
+    h2.lib().h2hip_debug_set_msm_max_chunk(ctypes.c_size_t(1000))
+    try:
+        assert np.array_equal(aff(h2, h2.best_multiexp(sc[0], bs)), want[0])
+        got = h2.best_multiexp_batch(sc, bs)
+        for j in range(3):
+            assert np.array_equal(aff(h2, got[j]), want[j])
+    finally:
+        h2.lib().h2hip_debug_set_msm_max_chunk(ctypes.c_size_t(0))
+
+
+def test_msm_2p26_quarters_property(h2):
+    """largest size of the metric range: 2^26 pairs (2^30 sorted pairs, 17 GB of workspace) equals the fold of its quarters"""
+    n = 1 << 26
+    ds = h2.gen_scalars_device(0x5EED0001, n)
+    dp = h2.gen_points_device(0x5EED0002, n)
+    full = aff(h2, h2.msm_device(ds, dp))
+    q = n // 4
+    parts = [h2.msm_device(ds[i * q:(i + 1) * q], dp[i * q:(i + 1) * q]) for i in range(4)]
+    assert np.array_equal(aff(h2, h2.g1_fold(np.stack(parts))), full)
