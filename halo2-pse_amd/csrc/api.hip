@@ -480,6 +480,106 @@ int h2hip_g1_fold(const uint64_t* partials_xyz, size_t k, uint64_t out_xyz[12]) 
     return 0;
 }
 
+int h2hip_g1_batch_normalize(const uint64_t* xyz, size_t k, uint64_t* xy) {
+    if (k && (!xyz || !xy)) {
+        set_error("g1_batch_normalize: null argument");
+        return H2HIP_EINVAL;
+    }
+    // Montgomery's trick on the z coordinates (identity points are skipped)
+    std::vector<Fe> prefix(k);
+    Fe acc = fe_one<Q>();
+    for (size_t i = 0; i < k; i++) {
+        Jac j;
+        memcpy(&j, xyz + 12 * i, 96);
+        prefix[i] = acc;
+        if (!fe_is_zero(j.z)) acc = fe_mul<Q>(acc, j.z);
+    }
+    Fe inv = fe_inv<Q>(acc);
+    for (size_t i = k; i-- > 0;) {
+        Jac j;
+        memcpy(&j, xyz + 12 * i, 96);
+        Affine a;
+        if (fe_is_zero(j.z)) {
+            a.x = fe_zero<Q>();
+            a.y = fe_zero<Q>();
+        } else {
+            Fe zi = fe_mul<Q>(inv, prefix[i]);
+            inv = fe_mul<Q>(inv, j.z);
+            Fe zi2 = fe_sqr<Q>(zi);
+            a.x = fe_mul<Q>(j.x, zi2);
+            a.y = fe_mul<Q>(j.y, fe_mul<Q>(zi2, zi));
+        }
+        memcpy(xy + 8 * i, &a, 64);
+    }
+    return 0;
+}
+
+int h2hip_device_alloc(size_t bytes, void** d_ptr) {
+    if (!d_ptr) {
+        set_error("device_alloc: null argument");
+        return H2HIP_EINVAL;
+    }
+    Entry en;
+    if (en.rc) return en.rc;
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        *d_ptr = nullptr;
+        set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return H2HIP_ENOMEM;
+    }
+    return 0;
+}
+
+int h2hip_device_free(void* d_ptr) {
+    Entry en;
+    if (en.rc) return en.rc;
+    H2_CHECK(hipDeviceSynchronize());
+    H2_CHECK(hipFree(d_ptr));
+    return 0;
+}
+
+int h2hip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream) {
+    if (bytes && (!d_dst || !h_src)) {
+        set_error("memcpy_h2d: null argument");
+        return H2HIP_EINVAL;
+    }
+    Entry en;
+    if (en.rc) return en.rc;
+    H2_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    H2_CHECK(hipStreamSynchronize((hipStream_t)stream));  // the source is a borrowed host slice
+    return 0;
+}
+
+int h2hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream) {
+    if (bytes && (!h_dst || !d_src)) {
+        set_error("memcpy_d2h: null argument");
+        return H2HIP_EINVAL;
+    }
+    Entry en;
+    if (en.rc) return en.rc;
+    H2_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    H2_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int h2hip_memset_zero(void* d_dst, size_t bytes, void* stream) {
+    if (bytes && !d_dst) {
+        set_error("memset_zero: null argument");
+        return H2HIP_EINVAL;
+    }
+    Entry en;
+    if (en.rc) return en.rc;
+    H2_CHECK(hipMemsetAsync(d_dst, 0, bytes, (hipStream_t)stream));
+    return 0;
+}
+
+int h2hip_stream_synchronize(void* stream) {
+    Entry en;
+    if (en.rc) return en.rc;
+    H2_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
 int h2hip_g1_to_affine(const uint64_t xyz[12], uint64_t xy[8]) {
     if (!xyz || !xy) {
         set_error("g1_to_affine: null argument");

@@ -79,6 +79,10 @@ int h2hip_msm_bn254_device(const void* d_scalars, const void* d_bases_xy, size_t
 int h2hip_msm_bn254_batch(const uint64_t* const* scalars, const uint64_t* bases_xy, size_t n, size_t count, uint64_t* out_xyz);
 int h2hip_msm_bn254_batch_device(const void* const* d_scalars, const void* d_bases_xy, size_t n, size_t count, uint64_t* out_xyz, void* stream);
 
+/* CurveExt::batch_normalize (plonk/prover.rs:368-371 normalises the advice commitments before writing them to the
+ * transcript): k Jacobian points -> k affine points with one field inversion; identity -> (0,0).  Host-side. */
+int h2hip_g1_batch_normalize(const uint64_t* xyz, size_t k, uint64_t* xy);
+
 /* Left fold of k Jacobian partial sums from the identity -- the fold at arithmetic.rs:153.
  * Multi-GPU MSM: each rank computes its shard's partial with h2hip_msm_bn254[_device], the
  * 96-byte partials are all-gathered (RCCL, bytes), and every rank folds them with this. */
@@ -123,6 +127,17 @@ int h2hip_extended_to_coeff_bn254_fr_device(void* d_a, uint32_t extended_k, cons
  * 2^extended_k coset evaluations, t_evaluations = the domain's inverted t(X) = X^n - 1 values (:84-124). */
 int h2hip_divide_by_vanishing_poly_bn254_fr(uint64_t* a, uint32_t extended_k, const uint64_t* t_evaluations, uint32_t t_len);
 int h2hip_divide_by_vanishing_poly_bn254_fr_device(void* d_a, uint32_t extended_k, const uint64_t* t_evaluations, uint32_t t_len, void* stream);
+
+/* ---- device-resident polynomials ---------------------------------------------------------
+ * A caller without a HIP binding (the Rust shim) keeps columns on the GPU across calls -- commit a column with
+ * h2hip_msm_bn254_device, then h2hip_ifft_bn254_fr_device / h2hip_coeff_to_extended_bn254_fr_device on the same
+ * buffer -- instead of crossing PCIe for every call.  Plain hipMalloc'd memory; `stream` as elsewhere. */
+int h2hip_device_alloc(size_t bytes, void** d_ptr);
+int h2hip_device_free(void* d_ptr);
+int h2hip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
+int h2hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
+int h2hip_memset_zero(void* d_dst, size_t bytes, void* stream);
+int h2hip_stream_synchronize(void* stream);
 
 /* ---- synthetic workload; same streams as oracle_gen_{scalars,points} ---- */
 

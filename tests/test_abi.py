@@ -75,3 +75,16 @@ def test_host_group_helpers_match_oracle(h2, oracle, golden):
     assert np.array_equal(h2.g1_to_affine(h2.g1_fold(np.stack([p, negj]))), np.zeros(8, dtype=np.uint64))
     dbl = h2.g1_to_affine(h2.g1_fold(np.stack([p, p])))
     assert np.array_equal(dbl, oracle.g1_to_affine(oracle.g1_add(p, p)))
+
+
+def test_batch_normalize_host(h2, oracle, golden):
+    import ctypes
+    sc, bs = golden["msm_33_scalars"], golden["msm_33_bases"]
+    pts = [oracle.best_multiexp(sc[i:i + 5], bs[i:i + 5]) for i in range(0, 30, 5)]
+    pts.insert(2, np.zeros(12, dtype=np.uint64))  # an identity in the middle (z = 0)
+    xyz = np.stack(pts)
+    out = np.zeros((len(pts), 8), dtype=np.uint64)
+    rc = h2.lib().h2hip_g1_batch_normalize(xyz.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(pts)), out.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    for i, p in enumerate(pts):
+        assert np.array_equal(out[i], oracle.g1_to_affine(p)), i

@@ -441,3 +441,42 @@ def test_msm_2p26_quarters_property(h2):
     q = n // 4
     parts = [h2.msm_device(ds[i * q:(i + 1) * q], dp[i * q:(i + 1) * q]) for i in range(4)]
     assert np.array_equal(aff(h2, h2.g1_fold(np.stack(parts))), full)
+
+
+def test_device_resident_column_flow(h2, oracle):
+    """SURVEY.md 8(f).2 through the buffer entry points a HIP-less caller would use: upload one column, commit it
+    (plonk/prover.rs:361-365), lagrange_to_coeff it in place (:487), coeff_to_extended it (evaluation.rs:311) -- one
+    upload, no PCIe traffic in between -- each step checked against the oracle."""
+    import ctypes
+    L = h2.lib()
+    k = 13
+    n = 1 << k
+    d, _ = oracle.domain_new(4, k)
+    col = _prover_like(oracle, n, 4242)
+    bases = oracle.gen_points(4243, n, num_threads=NT)
+    d_col, d_bases = ctypes.c_void_p(), ctypes.c_void_p()
+    en = 1 << d.extended_k
+    assert L.h2hip_device_alloc(ctypes.c_size_t(en * 32), ctypes.byref(d_col)) == 0
+    assert L.h2hip_device_alloc(ctypes.c_size_t(n * 64), ctypes.byref(d_bases)) == 0
+    try:
+        assert L.h2hip_memcpy_h2d(d_col, col.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n * 32), None) == 0
+        assert L.h2hip_memcpy_h2d(d_bases, bases.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n * 64), None) == 0
+        out = np.zeros(12, dtype=np.uint64)
+        assert L.h2hip_msm_bn254_device(d_col, d_bases, ctypes.c_size_t(n), out.ctypes.data_as(ctypes.c_void_p), None) == 0
+        assert np.array_equal(aff(h2, out), oracle.g1_to_affine(oracle.best_multiexp(col, bases, NT)))
+        fe = lambda name: np.ascontiguousarray(d.fe(name)).ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        keep = [d.fe(x) for x in ("omega_inv", "ifft_divisor", "extended_omega", "g_coset", "g_coset_inv")]
+        ptr = [np.ascontiguousarray(a) for a in keep]
+        p = [a.ctypes.data_as(ctypes.c_void_p) for a in ptr]
+        assert L.h2hip_ifft_bn254_fr_device(d_col, p[0], ctypes.c_uint32(k), p[1], None) == 0
+        coeff = np.zeros((n, 4), dtype=np.uint64)
+        assert L.h2hip_memcpy_d2h(coeff.ctypes.data_as(ctypes.c_void_p), d_col, ctypes.c_size_t(n * 32), None) == 0
+        assert np.array_equal(coeff, oracle.lagrange_to_coeff(d, col, NT))
+        assert L.h2hip_coeff_to_extended_bn254_fr_device(d_col, ctypes.c_uint32(k), ctypes.c_uint32(d.extended_k), p[2], p[3], p[4], None) == 0
+        ext = np.zeros((en, 4), dtype=np.uint64)
+        assert L.h2hip_memcpy_d2h(ext.ctypes.data_as(ctypes.c_void_p), d_col, ctypes.c_size_t(en * 32), None) == 0
+        assert np.array_equal(ext, oracle.coeff_to_extended(d, coeff, NT))
+        assert L.h2hip_stream_synchronize(None) == 0
+    finally:
+        L.h2hip_device_free(d_col)
+        L.h2hip_device_free(d_bases)
