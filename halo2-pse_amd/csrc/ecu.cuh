@@ -44,8 +44,8 @@ H2_HD XYZZu xyzzu_double_affine(const Fu& px, const Fu& py) {
     Fu s = fu_mul<QU>(x, v);
     Fu xx = fu_sqr<QU>(x);
     Fu m = fu_norm(fu_add(fu_dbl(xx), xx));
-    o.x = fu_norm(fu_sub(fu_sqr<QU>(m), fu_dbl(s)));
-    o.y = fu_norm(fu_sub(fu_mul<QU>(m, fu_norm(fu_sub(s, o.x))), fu_mul<QU>(w, y)));
+    o.x = fu_sqr_sub<QU>(m, fu_dbl(s));                       // M^2 - 2S, one reduction, normalised
+    o.y = fu_mul_sub<QU>(m, fu_sub(s, o.x), w, y);            // M*(S - X3) - W*Y1, one reduction
     o.zz = v;
     o.zzz = w;
     return o;
@@ -61,8 +61,8 @@ H2_HD XYZZu xyzzu_double(const XYZZu& p) {
     Fu s = fu_mul<QU>(p.x, v);
     Fu xx = fu_sqr<QU>(p.x);
     Fu m = fu_norm(fu_add(fu_dbl(xx), xx));
-    o.x = fu_norm(fu_sub(fu_sqr<QU>(m), fu_dbl(s)));
-    o.y = fu_norm(fu_sub(fu_mul<QU>(m, fu_norm(fu_sub(s, o.x))), fu_mul<QU>(w, p.y)));
+    o.x = fu_sqr_sub<QU>(m, fu_dbl(s));
+    o.y = fu_mul_sub<QU>(m, fu_sub(s, o.x), w, p.y);
     o.zz = fu_mul<QU>(v, p.zz);
     o.zzz = fu_mul<QU>(w, p.zzz);
     return o;
