@@ -33,7 +33,11 @@ H2_HD XYZZu xyzzu_identity() {
 
 H2_HD bool xyzzu_is_identity(const XYZZu& p) { return fu_all_zero(p.zz); }
 
+// The three functions of the bucket-accumulation inner loop take the field flavour as a template parameter: the
+// accumulate kernel instantiates them with FqUA (explicit-mad multiplier), everything else with QU.
+
 // 2 * (px, py) for a non-identity affine point in I-form (mdbl-2008-s-1)
+template <class QU = FqU>
 H2_HD XYZZu xyzzu_double_affine(const Fu& px, const Fu& py) {
     XYZZu o;
     const Fu one = fu_one_i<QU>();
@@ -71,6 +75,7 @@ H2_HD XYZZu xyzzu_double(const XYZZu& p) {
 // acc += (px, py): madd-2008-s.  (px, py) is a non-identity affine point in I-form with limbs of
 // magnitude < 2^29 (fu_from_ext output, possibly negated).  All exceptional cases of the group
 // law are exact: the cheap residue filter on P sends possible hits to an exact reduction.
+template <class QU = FqU>
 H2_HD void xyzzu_add_mixed(XYZZu& acc, const Fu& px, const Fu& py) {
     if (xyzzu_is_identity(acc)) {
         // first point of a bucket: bring 32x, 32y (|.| < 32 p) inside the accumulator bounds
@@ -88,7 +93,7 @@ H2_HD void xyzzu_add_mixed(XYZZu& acc, const Fu& px, const Fu& py) {
     if (fu_maybe_zero_mod_p<QU>(p_)) {
         if (fu_is_zero_mod_p<QU>(p_)) {
             if (fu_is_zero_mod_p<QU>(r)) {
-                acc = xyzzu_double_affine(px, py);
+                acc = xyzzu_double_affine<QU>(px, py);
             } else {
                 acc = xyzzu_identity();
             }
@@ -143,12 +148,13 @@ H2_HD void xyzzu_add(XYZZu& a, const XYZZu& b) {
 }
 
 // acc += p for an affine point in the reference's layout (E-form Fe, identity = (0,0)), optionally negated
+template <class QU = FqU>
 H2_HD void xyzzu_add_affine(XYZZu& acc, const Affine& p, bool negate) {
     if (affine_is_identity(p)) return;
     Fu px = fu_from_ext(p.x);
     Fu py = fu_from_ext(p.y);
     if (negate) py = fu_neg(py);
-    xyzzu_add_mixed(acc, px, py);
+    xyzzu_add_mixed<QU>(acc, px, py);
 }
 
 // I-form accumulator -> the E-form XYZZ of ec.cuh with canonical coordinates

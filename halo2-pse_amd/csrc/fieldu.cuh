@@ -32,6 +32,7 @@ struct Fu {
 
 struct FqU {  // base field, 29-bit limbs
     typedef FqP Sat;
+    static constexpr bool ASM = false;
     static constexpr uint32_t P[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u,
                                       0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
     static constexpr uint32_t INV = 0x04866389u;   // -p^-1 mod 2^29
@@ -46,6 +47,7 @@ struct FqU {  // base field, 29-bit limbs
 
 struct FrU {  // scalar field, 29-bit limbs
     typedef FrP Sat;
+    static constexpr bool ASM = false;
     static constexpr uint32_t P[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u,
                                       0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
     static constexpr uint32_t INV = 0x0fffffffu;
@@ -56,6 +58,18 @@ struct FrU {  // scalar field, 29-bit limbs
                                           0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u};
     static constexpr uint32_t P16[9] = {0x00000010u, 0x10fac9f8u, 0x05c2450fu, 0x1d090f37u, 0x185d2833u,
                                         0x0db40c0au, 0x0a6e1411u, 0x05c26340u, 0x030644e7u};
+};
+
+// Same fields with the multiplier's 162 multiply-adds written as explicit v_mad instructions in column order
+// (device only).  Measured (tools/mul_rate.hip): 179 instead of 162 G multiplies/s at >= 4 waves per SIMD, but a
+// lone wave is slower (673 vs 450 ns: one dependent chain, wait states between the asm statements), so only the
+// throughput-bound kernels (bucket accumulation, NTT passes) use these; everything latency-bound uses the plain
+// form, whose accumulator is pinned after each column by an empty asm so LLVM keeps the column order.
+struct FqUA : FqU {
+    static constexpr bool ASM = true;
+};
+struct FrUA : FrU {
+    static constexpr bool ASM = true;
 };
 
 #ifdef H2_FU_CHECK
@@ -173,45 +187,48 @@ H2_HD Fu fu_norm(const Fu& a) {
     return o;
 }
 
-// Montgomery product x*y/2^261 (mod p), product scanning with one 64-bit accumulator
+// acc += a * b (signed limbs) / acc += m * p (non-negative, p a compile-time limb of the modulus)
 template <class U>
-H2_HD Fu fu_mul(const Fu& a, const Fu& b) {
-#ifdef H2_FU_CHECK
-    {
-        int64_t ma = 0, mb = 0;
-        for (int i = 0; i < 9; i++) {
-            int64_t x = a.l[i] < 0 ? -(int64_t)a.l[i] : a.l[i], y = b.l[i] < 0 ? -(int64_t)b.l[i] : b.l[i];
-            if (x > ma) ma = x;
-            if (y > mb) mb = y;
-        }
-        __int128 bound = (__int128)9 * ma * mb + ((__int128)9 << 58) + ((__int128)1 << 36);
-        assert(bound < ((__int128)1 << 63));
+H2_HD void fu_mad_ss(int64_t& acc, int32_t a, int32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (U::ASM) {
+        uint64_t sink;
+        asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(sink) : "v"(a), "v"(b));
+        return;
     }
 #endif
-    int64_t acc = 0;
-    uint32_t m[9];
-    Fu r;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-#pragma unroll
-        for (int i = 0; i <= k; i++) acc += (int64_t)a.l[i] * (int64_t)b.l[k - i];
-#pragma unroll
-        for (int i = 0; i < k; i++) acc += (int64_t)m[i] * (int64_t)U::P[k - i];
-        m[k] = ((uint32_t)acc * U::INV) & H2_MASK29;
-        acc += (int64_t)m[k] * (int64_t)U::P[0];
-        acc >>= 29;  // exact: the low 29 bits are zero
+    acc += (int64_t)a * (int64_t)b;
+}
+
+template <class U>
+H2_HD void fu_mad_mp(int64_t& acc, uint32_t m, uint32_t p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (U::ASM) {
+        uint64_t sink;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(sink) : "v"(m), "s"(p));
+        return;
     }
-#pragma unroll
-    for (int k = 9; k < 17; k++) {
-#pragma unroll
-        for (int i = k - 8; i <= 8; i++) acc += (int64_t)a.l[i] * (int64_t)b.l[k - i];
-#pragma unroll
-        for (int i = k - 8; i <= 8; i++) acc += (int64_t)m[i] * (int64_t)U::P[k - i];
-        r.l[k - 9] = (int32_t)((uint32_t)acc & H2_MASK29);
-        acc >>= 29;
-    }
-    r.l[8] = (int32_t)acc;
-    return r;
+#endif
+    acc += (int64_t)m * (int64_t)p;
+}
+
+// keep the column order: without this LLVM reassociates the products into a row-wise multi-accumulator schedule
+// with ~35 more instructions (240 vs 205)
+template <class U>
+H2_HD void fu_column_done(int64_t& acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (!U::ASM) asm("" : "+v"(acc));
+#endif
+    (void)acc;
+}
+
+// Montgomery product x*y/2^261 (mod p), product scanning with one 64-bit accumulator
+template <class U, bool SQR, bool TWO, bool HI>
+H2_HD Fu fu_fused(const Fu& a, const Fu& b, const Fu& c, const Fu& d, const Fu& h);
+
+template <class U>
+H2_HD Fu fu_mul(const Fu& a, const Fu& b) {
+    return fu_fused<U, false, false, false>(a, b, a, a, a);
 }
 
 // General fused form: (a*b [- c*d] [- h * 2^261]) / 2^261 (mod p) with ONE Montgomery reduction.
@@ -256,27 +273,29 @@ H2_HD Fu fu_fused(const Fu& a, const Fu& b, const Fu& c, const Fu& d, const Fu& 
 #pragma unroll
             for (int i = lo; i <= hi; i++) {
                 int j = k - i;
-                if (i < j) acc += (int64_t)a2[i] * (int64_t)a.l[j];
-                else if (i == j) acc += (int64_t)a.l[i] * (int64_t)a.l[i];
+                if (i < j) fu_mad_ss<U>(acc, a2[i], a.l[j]);
+                else if (i == j) fu_mad_ss<U>(acc, a.l[i], a.l[i]);
             }
         } else {
 #pragma unroll
-            for (int i = lo; i <= hi; i++) acc += (int64_t)a.l[i] * (int64_t)b.l[k - i];
+            for (int i = lo; i <= hi; i++) fu_mad_ss<U>(acc, a.l[i], b.l[k - i]);
         }
         if (TWO) {
 #pragma unroll
-            for (int i = lo; i <= hi; i++) acc += (int64_t)nc[i] * (int64_t)d.l[k - i];
+            for (int i = lo; i <= hi; i++) fu_mad_ss<U>(acc, nc[i], d.l[k - i]);
         }
         if (k < 9) {
 #pragma unroll
-            for (int i = 0; i < k; i++) acc += (int64_t)m[i] * (int64_t)U::P[k - i];
+            for (int i = 0; i < k; i++) fu_mad_mp<U>(acc, m[i], U::P[k - i]);
+            fu_column_done<U>(acc);
             m[k] = ((uint32_t)acc * U::INV) & H2_MASK29;
-            acc += (int64_t)m[k] * (int64_t)U::P[0];
+            fu_mad_mp<U>(acc, m[k], U::P[0]);
             acc >>= 29;  // exact
         } else {
 #pragma unroll
-            for (int i = k - 8; i <= 8; i++) acc += (int64_t)m[i] * (int64_t)U::P[k - i];
+            for (int i = k - 8; i <= 8; i++) fu_mad_mp<U>(acc, m[i], U::P[k - i]);
             if (HI) acc -= (int64_t)h.l[k - 9];
+            fu_column_done<U>(acc);
             r.l[k - 9] = (int32_t)((uint32_t)acc & H2_MASK29);
             acc >>= 29;
         }

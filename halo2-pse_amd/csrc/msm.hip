@@ -153,9 +153,10 @@ struct HeavyChunk {
 };
 
 // one bucket-accumulation step: acc += (+/-) bases[index], in the unsaturated arithmetic of ecu.cuh
+template <class F>
 __device__ __forceinline__ void accum_signed(XYZZu& acc, const Affine* __restrict__ bases, uint32_t v) {
     Affine p = bases[v & 0x7fffffffu];
-    xyzzu_add_affine(acc, p, (v >> 31) != 0);
+    xyzzu_add_affine<F>(acc, p, (v >> 31) != 0);
 }
 
 // K2: one lane per bucket
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__(256) msm_accum_kernel(const Affine* __restrict
             heavy_chunks[slot + q] = ch;
         }
     } else {
-        for (uint32_t i = s; i < e; i++) accum_signed(acc, bases, vals[i]);
+        for (uint32_t i = s; i < e; i++) accum_signed<FqUA>(acc, bases, vals[i]);  // throughput-bound: explicit-mad multiplier
     }
     buckets[b] = acc;
 }
@@ -209,7 +210,7 @@ __global__ void __launch_bounds__(256) msm_heavy_chunk_kernel(const Affine* __re
     for (uint32_t ci = blockIdx.x; ci < total; ci += gridDim.x) {
         HeavyChunk ch = heavy_chunks[ci];
         XYZZu acc = xyzzu_identity();
-        for (uint32_t i = ch.begin + threadIdx.x; i < ch.end; i += blockDim.x) accum_signed(acc, bases, vals[i]);
+        for (uint32_t i = ch.begin + threadIdx.x; i < ch.end; i += blockDim.x) accum_signed<FqU>(acc, bases, vals[i]);
         XYZZu r = block_tree_sum(acc, sh);
         if (threadIdx.x == 0) chunk_sums[ci] = r;
         __syncthreads();

@@ -47,7 +47,7 @@ __device__ __forceinline__ Fu tw_pow(const NttPass& p, uint64_t e) {
     uint32_t lo = (uint32_t)(e & ((1ull << p.lo_bits) - 1));
     uint64_t hi = e >> p.lo_bits;
     Fu a = p.tw_lo[lo];
-    if (hi) a = fu_mul<FrU>(a, p.tw_hi[hi]);
+    if (hi) a = fu_mul<FrUA>(a, p.tw_hi[hi]);
     return a;
 }
 
@@ -83,12 +83,12 @@ __device__ __forceinline__ void dft_lds(Fu* x, const Fu* wtab, uint32_t s, uint3
             Fu x0 = x[base], x1 = x[base + h], x2 = x[base + 2 * h], x3 = x[base + 3 * h];
             if (log_h) {
                 Fu wa = wtab[off << (s - 1 - log_h)];
-                x1 = fu_mul<FrU>(x1, wa);
-                x3 = fu_mul<FrU>(x3, wa);
+                x1 = fu_mul<FrUA>(x1, wa);
+                x3 = fu_mul<FrUA>(x3, wa);
             }
             Fu y0 = fu_add(x0, x1), y1 = fu_sub(x0, x1), y2 = fu_add(x2, x3), y3 = fu_sub(x2, x3);
-            Fu u2 = fu_mul<FrU>(y2, wtab[off << (s - 2 - log_h)]);
-            Fu u3 = fu_mul<FrU>(y3, wtab[(off + h) << (s - 2 - log_h)]);
+            Fu u2 = fu_mul<FrUA>(y2, wtab[off << (s - 2 - log_h)]);
+            Fu u3 = fu_mul<FrUA>(y3, wtab[(off + h) << (s - 2 - log_h)]);
             x[base] = fu_norm(fu_add(y0, u2));
             x[base + 2 * h] = fu_norm(fu_sub(y0, u2));
             x[base + h] = fu_norm(fu_add(y1, u3));
@@ -107,7 +107,7 @@ __device__ __forceinline__ void dft_lds(Fu* x, const Fu* wtab, uint32_t s, uint3
             uint32_t i0 = (col << s) + (blk << (log_h + 1)) + off;
             uint32_t i1 = i0 + h;
             Fu a = x[i0], t = x[i1];
-            if (log_h) t = fu_mul<FrU>(t, wtab[off << (s - 1 - log_h)]);
+            if (log_h) t = fu_mul<FrUA>(t, wtab[off << (s - 1 - log_h)]);
             x[i0] = fu_add(a, t);
             x[i1] = fu_sub(a, t);
         }
@@ -121,7 +121,7 @@ __device__ __forceinline__ Fu ntt_load(const NttPass& p, uint64_t gi) {
         Fu v = fu_slice(p.src[gi]);
         if (p.in_scale) {
             uint32_t m = (uint32_t)(gi % 3);
-            if (m) v = fu_mul<FrU>(v, pick3(p.in3, m));
+            if (m) v = fu_mul<FrUA>(v, pick3(p.in3, m));
         }
         return v;
     }
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_strided_kernel(NttPass p) {
         uint32_t k = idx >> p.log_j, jj = idx & (J - 1);
         uint64_t lo = lo0 + jj;
         uint64_t e = ((uint64_t)k * lo) << (p.log_n - p.log_m);  // w_M^(k*lo) = omega^((N/M)*k*lo)
-        p.dst[base + ((uint64_t)k << log_l) + lo] = fu_mul_canon<FrU>(x[(jj << p.s) + k], tw_pow(p, e));
+        p.dst[base + ((uint64_t)k << log_l) + lo] = fu_mul_canon<FrUA>(x[(jj << p.s) + k], tw_pow(p, e));
     }
 }
 
@@ -173,12 +173,12 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_final_kernel(NttPass p) {
     __syncthreads();
     dft_lds(x, wtab, p.s, p.log_j);
     const uint32_t log_nb = p.log_n - p.s;
-    const Fu one_i = fu_one_i<FrU>();
+    const Fu one_i = fu_one_i<FrUA>();
     for (uint32_t idx = threadIdx.x; idx < (R << p.log_j); idx += NTT_THREADS) {
         uint32_t k = idx >> p.log_j, jj = idx & (J - 1);
         uint64_t oi = ((uint64_t)k << log_nb) + (g << p.log_j) + jj;
         Fu c = p.out_scale ? pick3(p.out3, (uint32_t)(oi % 3)) : one_i;
-        p.dst[oi] = fu_mul_canon<FrU>(x[(jj << p.s) + k], c);
+        p.dst[oi] = fu_mul_canon<FrUA>(x[(jj << p.s) + k], c);
     }
 }
 
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_final_kernel(NttPass p) {
 __global__ void ntt_n1_kernel(NttPass p) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         Fu v = ntt_load(p, 0);
-        p.dst[0] = fu_mul_canon<FrU>(v, p.out_scale ? p.out3[0] : fu_one_i<FrU>());
+        p.dst[0] = fu_mul_canon<FrUA>(v, p.out_scale ? p.out3[0] : fu_one_i<FrUA>());
     }
 }
 

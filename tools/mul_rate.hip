@@ -74,6 +74,100 @@ __device__ __forceinline__ Fu fu_mul3(const Fu& a, const Fu& b) {
     return r;
 }
 
+// variant 3: column order, explicit v_mad instructions (one accumulator), nothing else left to the compiler
+__device__ __forceinline__ void mad_ss(int64_t& acc, int32_t a, int32_t b) { uint64_t sink; asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(sink) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void mad_us(int64_t& acc, uint32_t a, uint32_t b) { uint64_t sink; asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(sink) : "v"(a), "s"(b)); }
+template <class U>
+__device__ __forceinline__ Fu fu_mul4(const Fu& a, const Fu& b) {
+    int64_t acc = 0;
+    uint32_t m[9];
+    Fu r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) mad_ss(acc, a.l[i], b.l[k - i]);
+#pragma unroll
+        for (int i = 0; i < k; i++) mad_us(acc, m[i], U::P[k - i]);
+        m[k] = ((uint32_t)acc * U::INV) & H2_MASK29;
+        mad_us(acc, m[k], U::P[0]);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) mad_ss(acc, a.l[i], b.l[k - i]);
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) mad_us(acc, m[i], U::P[k - i]);
+        r.l[k - 9] = (int32_t)((uint32_t)acc & H2_MASK29);
+        acc >>= 29;
+    }
+    r.l[8] = (int32_t)acc;
+    return r;
+}
+
+// variant 5: plain C in column order with an empty-asm barrier on the accumulator after every column, which stops
+// LLVM from reassociating the 162 products into its row-wise multi-accumulator form
+template <class U>
+__device__ __forceinline__ Fu fu_mul6(const Fu& a, const Fu& b) {
+    int64_t acc = 0;
+    uint32_t m[9];
+    Fu r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (int64_t)a.l[i] * (int64_t)b.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (int64_t)m[i] * (int64_t)U::P[k - i];
+        asm("" : "+v"(acc));
+        m[k] = ((uint32_t)acc * U::INV) & H2_MASK29;
+        acc += (int64_t)m[k] * (int64_t)U::P[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) acc += (int64_t)a.l[i] * (int64_t)b.l[k - i];
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) acc += (int64_t)m[i] * (int64_t)U::P[k - i];
+        asm("" : "+v"(acc));
+        r.l[k - 9] = (int32_t)((uint32_t)acc & H2_MASK29);
+        acc >>= 29;
+    }
+    r.l[8] = (int32_t)acc;
+    return r;
+}
+
+// variant 4: as 3 with two accumulators per column (a*b chain, m*p chain)
+template <class U>
+__device__ __forceinline__ Fu fu_mul5(const Fu& a, const Fu& b) {
+    int64_t carry = 0;
+    uint32_t m[9];
+    Fu r;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        int64_t s0 = carry, s1 = 0;
+        const int lo = k > 8 ? k - 8 : 0, hi = k < 8 ? k : 8;
+#pragma unroll
+        for (int i = lo; i <= hi; i++) mad_ss(s0, a.l[i], b.l[k - i]);
+        if (k < 9) {
+#pragma unroll
+            for (int i = 0; i < k; i++) mad_us(s1, m[i], U::P[k - i]);
+            int64_t acc = s0 + s1;
+            m[k] = ((uint32_t)acc * U::INV) & H2_MASK29;
+            mad_us(acc, m[k], U::P[0]);
+            carry = acc >> 29;
+        } else {
+#pragma unroll
+            for (int i = k - 8; i <= 8; i++) mad_us(s1, m[i], U::P[k - i]);
+            int64_t acc = s0 + s1;
+            r.l[k - 9] = (int32_t)((uint32_t)acc & H2_MASK29);
+            carry = acc >> 29;
+        }
+    }
+    r.l[8] = (int32_t)carry;
+    return r;
+}
+
 template <int V>
 __global__ void __launch_bounds__(256) k(Fu* a, int iters) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,6 +176,9 @@ __global__ void __launch_bounds__(256) k(Fu* a, int iters) {
         if (V == 0) x = fu_mul<FqU>(x, y);
         if (V == 1) x = fu_mul2<FqU>(x, y);
         if (V == 2) x = fu_mul3<FqU>(x, y);
+        if (V == 3) x = fu_mul4<FqU>(x, y);
+        if (V == 4) x = fu_mul5<FqU>(x, y);
+        if (V == 5) x = fu_mul6<FqU>(x, y);
     }
     a[i] = x;
 }
@@ -112,6 +209,6 @@ int main() {
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     int cus = prop.multiProcessorCount;
     Fu* d; hipMalloc(&d, (size_t)cus * 8 * 256 * sizeof(Fu) + 64); hipMemset(d, 1, (size_t)cus * 8 * 256 * sizeof(Fu) + 64);
-    for (int w : {1, 2, 4, 8}) { run<0>(d, w, cus); run<1>(d, w, cus); run<2>(d, w, cus); }
+    for (int w : {1, 4, 8}) { run<0>(d, w, cus); run<3>(d, w, cus); run<5>(d, w, cus); }
     return 0;
 }
