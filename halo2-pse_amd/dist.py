@@ -5,6 +5,8 @@ rank.  RCCL has no elliptic-curve reduction operator, so "reduce" = gather bytes
 torch.distributed is the transport only (backend "nccl" is RCCL on ROCm; "gloo" in CPU tests)."""
 import numpy as np
 
+_bufs = {}
+
 
 def shard_range(n, rank, world):
     """contiguous shard [lo, hi) of n pairs for `rank`; the last rank takes the remainder"""
@@ -16,14 +18,17 @@ def shard_range(n, rank, world):
 
 def allgather_fold(partial_xyz, h2, device=None, group=None):
     """partial_xyz: (12,) uint64 Jacobian partial of this rank -> (12,) uint64 fold over all ranks,
-    identical on every rank."""
+    identical on every rank.  One collective (all_gather_into_tensor of 12 int64 per rank) and one
+    device-to-host copy per call; the staging tensors are reused."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    mine = torch.from_numpy(np.ascontiguousarray(partial_xyz, dtype=np.uint64).view(np.int64).copy())
-    if device is not None:
-        mine = mine.to(device)
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine, group=group)
-    parts = np.stack([g.cpu().numpy().view(np.uint64) for g in gathered])
+    key = (str(device), world, id(group))
+    if key not in _bufs:
+        dev = device if device is not None else "cpu"
+        _bufs[key] = (torch.empty(12, dtype=torch.int64, device=dev), torch.empty(12 * world, dtype=torch.int64, device=dev))
+    mine, gathered = _bufs[key]
+    mine.copy_(torch.from_numpy(np.ascontiguousarray(partial_xyz, dtype=np.uint64).view(np.int64)))
+    dist.all_gather_into_tensor(gathered, mine, group=group)
+    parts = gathered.cpu().numpy().view(np.uint64).reshape(world, 12)
     return h2.g1_fold(parts)
