@@ -34,6 +34,8 @@ from __graft_entry__ import load_pkg  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 MSM_BYTES_PER_PAIR = 96  # 32 B scalar + 64 B affine point, read once
 NTT_BYTES_PER_ELEM = 64  # one 32 B read + one 32 B write per transform
+FIELD_MUL_PER_BUCKET_ADD = 9.2  # XYZZ mixed add: 7 products + 2 squares + one two-product single-reduction form (csrc/ecu.cuh)
+FIELD_MUL_PEAK_G = 179.0  # measured peak of csrc/fieldu.cuh's multiplier on MI355X, G multiplies/s (tools/mul_rate.hip)
 
 
 def pmc_traffic(workload):
@@ -213,6 +215,13 @@ def main():
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                     "traffic": pmc_traffic("msm_2p%d" % args.log_n), "kernel": "msm_accum_kernel", "kernel_ms": accum_ms,
                     "algorithmic_bytes_per_launch": MSM_BYTES_PER_PAIR * n}
+        # second roofline, the one that actually binds: 256-bit modular multiplies per second against the
+        # multiplier's measured chip-wide peak (tools/mul_rate.hip: 179 G/s for the explicit-mad form at >= 4 waves/SIMD)
+        valu = None
+        if accum_ms:
+            gmul = n * W * FIELD_MUL_PER_BUCKET_ADD / (accum_ms * 1e-3) / 1e9
+            valu = {"bound": "valu-int", "kernel": "msm_accum_kernel", "field_mul_per_add": FIELD_MUL_PER_BUCKET_ADD,
+                    "achieved": gmul, "peak": FIELD_MUL_PEAK_G, "unit": "Gmul/s", "frac": gmul / FIELD_MUL_PEAK_G}
         out = {
             "metric": "bn254_msm_g1_adds_per_sec",
             "value": adds / elapsed,
@@ -231,6 +240,7 @@ def main():
             "pairs_per_s": world * n * args.steps / elapsed,
             "stage_ms": stages,
             "roofline": roof,
+            "valu_roofline": valu,
             "cpu_baseline": cpu,
             "parity_vs_cpu": parity,
             "batched": batched,
