@@ -321,6 +321,7 @@ void h2hip_shutdown(void) {
     c->msm_bases.release();
     c->host_ws.release();
     c->misc.release();
+    c->evalh_ws.release();
     (void)hipStreamDestroy(c->stream);
     c->stream = nullptr;
     for (auto e : c->aux_events) (void)hipEventDestroy(e);
@@ -734,6 +735,16 @@ int h2hip_divide_by_vanishing_poly_bn254_fr(uint64_t* a, uint32_t extended_k, co
     H2_CHECK(hipMemcpyAsync(a, c->ntt_io.p, bytes, hipMemcpyDeviceToHost, c->stream));
     H2_CHECK(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+int h2hip_evaluate_h_bn254(const h2hip_evalh_desc* desc, uint64_t* values) {
+    if (!desc || !values) {
+        set_error("evaluate_h: null argument");
+        return H2HIP_EINVAL;
+    }
+    Entry en;
+    if (en.rc) return en.rc;
+    return evaluate_h_host(en.c, desc, values);
 }
 
 int h2hip_gen_scalars_device(uint64_t seed, uint64_t start, size_t n, void* d_out, void* stream) {

@@ -139,6 +139,83 @@ int h2hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream)
 int h2hip_memset_zero(void* d_dst, size_t bytes, void* stream);
 int h2hip_stream_synchronize(void* stream);
 
+/* ---- Evaluator::evaluate_h: plonk/evaluation.rs:280-522 ---------------------------------------
+ * The quotient numerator h(X) on the extended coset: per row, the custom-gate graph (GraphEvaluator, :191-201,
+ * :708-749), the permutation argument's constraints (:362-441) and every lookup's constraints (:443-518), folded
+ * with powers of y.  The reference's Rust structures are passed flattened:
+ *   ValueSource  (evaluation.rs:37-60)   -> h2hip_value_source {kind, a, b}
+ *   Calculation + CalculationInfo (:108-127, :213-219) -> h2hip_calculation
+ *   GraphEvaluator (:191-201)            -> h2hip_graph
+ * One call handles one circuit instance; `values` is read and written (the reference folds all instances into
+ * the same polynomial, :326-332), so pass zeros for the first instance. */
+enum {
+    H2HIP_VS_CONSTANT = 0, H2HIP_VS_INTERMEDIATE = 1, H2HIP_VS_FIXED = 2, H2HIP_VS_ADVICE = 3, H2HIP_VS_INSTANCE = 4,
+    H2HIP_VS_CHALLENGE = 5, H2HIP_VS_BETA = 6, H2HIP_VS_GAMMA = 7, H2HIP_VS_THETA = 8, H2HIP_VS_Y = 9, H2HIP_VS_PREVIOUS = 10
+};
+enum {
+    H2HIP_CALC_ADD = 0, H2HIP_CALC_SUB = 1, H2HIP_CALC_MUL = 2, H2HIP_CALC_SQUARE = 3, H2HIP_CALC_DOUBLE = 4,
+    H2HIP_CALC_NEGATE = 5, H2HIP_CALC_HORNER = 6, H2HIP_CALC_STORE = 7
+};
+enum { H2HIP_ANY_ADVICE = 0, H2HIP_ANY_FIXED = 1, H2HIP_ANY_INSTANCE = 2 };
+
+typedef struct {
+    uint32_t kind; /* H2HIP_VS_* */
+    uint32_t a;    /* constant / intermediate / challenge index, or column index */
+    uint32_t b;    /* index into the graph's rotations for Fixed / Advice / Instance */
+} h2hip_value_source;
+
+typedef struct {
+    uint32_t op;     /* H2HIP_CALC_* */
+    uint32_t target; /* intermediate written (CalculationInfo::target) */
+    h2hip_value_source x, y; /* operands; Horner: x = start value, y = factor */
+    uint32_t parts_offset, parts_count; /* Horner parts in h2hip_graph::parts */
+} h2hip_calculation;
+
+typedef struct {
+    const uint64_t* constants; /* n_constants x 4 */
+    uint32_t n_constants;
+    const int32_t* rotations;
+    uint32_t n_rotations;
+    const h2hip_calculation* calculations;
+    uint32_t n_calculations;
+    const h2hip_value_source* parts;
+    uint32_t n_parts;
+    uint32_t num_intermediates; /* <= 256 in this engine */
+} h2hip_graph;
+
+typedef struct {
+    /* domain (poly/domain.rs:18-34) */
+    uint32_t k, extended_k;
+    const uint64_t *extended_omega, *g_coset, *g_coset_inv;
+    /* columns: pk.fixed_cosets (extended), advice / instance polynomials in coefficient form (2^k each; their cosets
+     * are formed here with coeff_to_extended as at evaluation.rs:306-323) */
+    uint32_t n_fixed, n_advice, n_instance, n_challenges;
+    const uint64_t* const* fixed_cosets;
+    const uint64_t* const* advice_polys;
+    const uint64_t* const* instance_polys;
+    const uint64_t* challenges;              /* n_challenges x 4 */
+    const uint64_t *y, *beta, *gamma, *theta;
+    const uint64_t *l0, *l_last, *l_active_row; /* pk.l0 / l_last / l_active_row, extended */
+    h2hip_graph custom_gates;                /* Evaluator::custom_gates */
+    /* permutation argument (evaluation.rs:362-441); n_perm_sets == 0 skips it */
+    uint32_t n_perm_sets, n_perm_columns, chunk_len; /* chunk_len = cs.degree() - 2 */
+    int32_t last_rotation;                   /* -(blinding_factors + 1) */
+    const uint64_t* const* perm_product_cosets; /* sets[i].permutation_product_coset, extended */
+    const uint32_t* perm_column_kind;        /* H2HIP_ANY_* of p.columns[j] */
+    const uint32_t* perm_column_index;
+    const uint64_t* const* perm_cosets;      /* pk.permutation.cosets[j], extended */
+    const uint64_t *zeta, *delta;            /* Fr::ZETA, Fr::DELTA */
+    /* lookups (evaluation.rs:443-518) */
+    uint32_t n_lookups;
+    const h2hip_graph* lookup_graphs;        /* Evaluator::lookups[n] */
+    const uint64_t* const* lookup_product_polys;        /* coefficient form, 2^k each */
+    const uint64_t* const* lookup_permuted_input_polys;
+    const uint64_t* const* lookup_permuted_table_polys;
+} h2hip_evalh_desc;
+
+/* values: 2^extended_k elements, in/out, host memory */
+int h2hip_evaluate_h_bn254(const h2hip_evalh_desc* desc, uint64_t* values);
+
 /* ---- synthetic workload; same streams as oracle_gen_{scalars,points} ---- */
 
 int h2hip_gen_scalars_device(uint64_t seed, uint64_t start, size_t n, void* d_out, void* stream);

@@ -907,3 +907,193 @@ void oracle_gen_parallel(int kind, uint64_t seed, size_t n, void *out, int num_t
     free(th);
     free(jobs);
 }
+
+/* ------------------------------------------------------------------ evaluate_h (plonk/evaluation.rs:280-522) */
+#include "../include/halo2hip.h"   /* the flattened ValueSource / Calculation / GraphEvaluator structures */
+
+typedef struct {
+    const h2hip_evalh_desc *d;
+    const fe *const *fixed;   /* extended cosets */
+    fe **advice, **instance;  /* extended cosets computed here */
+    fe beta, gamma, theta, y;
+    size_t size;
+    int32_t rot_scale, isize;
+} evalh_ctx;
+
+/* get_rotation_idx (evaluation.rs:32-34) */
+static inline size_t get_rotation_idx(size_t idx, int32_t rot, int32_t rot_scale, int32_t isize) {
+    int64_t v = ((int64_t)idx + (int64_t)rot * rot_scale) % isize;
+    if (v < 0) v += isize;
+    return (size_t)v;
+}
+
+/* ValueSource::get (evaluation.rs:68-103) */
+static fe vs_get(const evalh_ctx *c, const h2hip_graph *g, const h2hip_value_source *v, const size_t *rotations, const fe *inter,
+                 const fe *previous) {
+    switch (v->kind) {
+    case H2HIP_VS_CONSTANT: return ((const fe *)g->constants)[v->a];
+    case H2HIP_VS_INTERMEDIATE: return inter[v->a];
+    case H2HIP_VS_FIXED: return c->fixed[v->a][rotations[v->b]];
+    case H2HIP_VS_ADVICE: return c->advice[v->a][rotations[v->b]];
+    case H2HIP_VS_INSTANCE: return c->instance[v->a][rotations[v->b]];
+    case H2HIP_VS_CHALLENGE: return ((const fe *)c->d->challenges)[v->a];
+    case H2HIP_VS_BETA: return c->beta;
+    case H2HIP_VS_GAMMA: return c->gamma;
+    case H2HIP_VS_THETA: return c->theta;
+    case H2HIP_VS_Y: return c->y;
+    default: return *previous; /* PreviousValue */
+    }
+}
+
+/* GraphEvaluator::evaluate (evaluation.rs:708-749) with Calculation::evaluate (:129-178) */
+static fe graph_evaluate(const evalh_ctx *c, const h2hip_graph *g, size_t *rotations, fe *inter, const fe *previous, size_t idx) {
+    for (uint32_t r = 0; r < g->n_rotations; r++) rotations[r] = get_rotation_idx(idx, g->rotations[r], c->rot_scale, c->isize); /* :725-727 */
+    for (uint32_t q = 0; q < g->n_calculations; q++) {                                                                        /* :730-745 */
+        const h2hip_calculation *cl = &g->calculations[q];
+        fe a = vs_get(c, g, &cl->x, rotations, inter, previous), b, out;
+        switch (cl->op) {
+        case H2HIP_CALC_ADD: b = vs_get(c, g, &cl->y, rotations, inter, previous); fe_add(&out, &a, &b, &FR); break;
+        case H2HIP_CALC_SUB: b = vs_get(c, g, &cl->y, rotations, inter, previous); fe_sub(&out, &a, &b, &FR); break;
+        case H2HIP_CALC_MUL: b = vs_get(c, g, &cl->y, rotations, inter, previous); fe_mul(&out, &a, &b, &FR); break;
+        case H2HIP_CALC_SQUARE: fe_sqr(&out, &a, &FR); break;
+        case H2HIP_CALC_DOUBLE: fe_dbl(&out, &a, &FR); break;
+        case H2HIP_CALC_NEGATE: fe_neg(&out, &a, &FR); break;
+        case H2HIP_CALC_HORNER: {                                                                                              /* :166-173 */
+            fe factor = vs_get(c, g, &cl->y, rotations, inter, previous);
+            out = a;
+            for (uint32_t t = 0; t < cl->parts_count; t++) {
+                fe part = vs_get(c, g, &g->parts[cl->parts_offset + t], rotations, inter, previous);
+                fe_mul(&out, &out, &factor, &FR);
+                fe_add(&out, &out, &part, &FR);
+            }
+            break;
+        }
+        default: out = a; /* Store */
+        }
+        inter[cl->target] = out;
+    }
+    if (g->n_calculations) return inter[g->calculations[g->n_calculations - 1].target];                                        /* :748-752 */
+    fe z = {{0, 0, 0, 0}};
+    return z;
+}
+
+static const fe *perm_column(const evalh_ctx *c, uint32_t j) {                                                                 /* :404-408 */
+    uint32_t kind = c->d->perm_column_kind[j], col = c->d->perm_column_index[j];
+    if (kind == H2HIP_ANY_ADVICE) return c->advice[col];
+    if (kind == H2HIP_ANY_FIXED) return c->fixed[col];
+    return c->instance[col];
+}
+
+int oracle_evaluate_h(const h2hip_evalh_desc *d, fe *values) {
+    oracle_init();
+    evalh_ctx c;
+    memset(&c, 0, sizeof(c));
+    c.d = d;
+    c.size = (size_t)1 << d->extended_k;
+    c.rot_scale = 1 << (d->extended_k - d->k);                                                                                 /* :295 */
+    c.isize = (int32_t)c.size;
+    c.fixed = (const fe *const *)d->fixed_cosets;
+    memcpy(&c.beta, d->beta, 32); memcpy(&c.gamma, d->gamma, 32); memcpy(&c.theta, d->theta, 32); memcpy(&c.y, d->y, 32);
+    oracle_domain dom;
+    memset(&dom, 0, sizeof(dom));
+    dom.k = d->k; dom.extended_k = d->extended_k; dom.n = (uint64_t)1 << d->k;
+    memcpy(&dom.extended_omega, d->extended_omega, 32); memcpy(&dom.g_coset, d->g_coset, 32); memcpy(&dom.g_coset_inv, d->g_coset_inv, 32);
+    const size_t size = c.size;
+    /* :306-323 advice and instance cosets */
+    c.advice = (fe **)calloc(d->n_advice + 1, sizeof(fe *));
+    c.instance = (fe **)calloc(d->n_instance + 1, sizeof(fe *));
+    for (uint32_t i = 0; i < d->n_advice; i++) { c.advice[i] = (fe *)malloc(size * sizeof(fe)); oracle_coeff_to_extended(&dom, (const fe *)d->advice_polys[i], c.advice[i], 1); }
+    for (uint32_t i = 0; i < d->n_instance; i++) { c.instance[i] = (fe *)malloc(size * sizeof(fe)); oracle_coeff_to_extended(&dom, (const fe *)d->instance_polys[i], c.instance[i], 1); }
+    const fe *l0 = (const fe *)d->l0, *l_last = (const fe *)d->l_last, *l_active = (const fe *)d->l_active_row;
+    const fe one = FR.r;
+    fe extended_omega; memcpy(&extended_omega, d->extended_omega, 32);
+    size_t *rotations = (size_t *)malloc(4096 * sizeof(size_t));
+    fe *inter = (fe *)malloc(65536 * sizeof(fe));
+    /* :334-360 custom gates */
+    for (size_t idx = 0; idx < size; idx++) {
+        fe prev = values[idx];
+        values[idx] = graph_evaluate(&c, &d->custom_gates, rotations, inter, &prev, idx);
+    }
+    /* :362-441 permutations */
+    if (d->n_perm_sets) {
+        fe zeta, delta, delta_start, beta_term = FR.r, t, u;
+        memcpy(&zeta, d->zeta, 32); memcpy(&delta, d->delta, 32);
+        fe_mul(&delta_start, &c.beta, &zeta, &FR);                                                                             /* :368 */
+        const fe *const *z = (const fe *const *)d->perm_product_cosets;
+        const fe *first = z[0], *last = z[d->n_perm_sets - 1];
+        for (size_t idx = 0; idx < size; idx++) {
+            size_t r_next = get_rotation_idx(idx, 1, c.rot_scale, c.isize);
+            size_t r_last = get_rotation_idx(idx, d->last_rotation, c.rot_scale, c.isize);
+            fe *value = &values[idx];
+            /* l_0(X) * (1 - z_0(X)) = 0  :382-386 */
+            fe_sub(&t, &one, &first[idx], &FR); fe_mul(&t, &t, &l0[idx], &FR);
+            fe_mul(value, value, &c.y, &FR); fe_add(value, value, &t, &FR);
+            /* l_last(X) * (z_l(X)^2 - z_l(X)) = 0  :387-393 */
+            fe_mul(&t, &last[idx], &last[idx], &FR); fe_sub(&t, &t, &last[idx], &FR); fe_mul(&t, &t, &l_last[idx], &FR);
+            fe_mul(value, value, &c.y, &FR); fe_add(value, value, &t, &FR);
+            /* l_0(X) * (z_i(X) - z_{i-1}(omega^(last) X)) = 0  :394-404 */
+            for (uint32_t s = 1; s < d->n_perm_sets; s++) {
+                fe_sub(&t, &z[s][idx], &z[s - 1][r_last], &FR); fe_mul(&t, &t, &l0[idx], &FR);
+                fe_mul(value, value, &c.y, &FR); fe_add(value, value, &t, &FR);
+            }
+            /* :405-438 */
+            fe current_delta;
+            fe_mul(&current_delta, &delta_start, &beta_term, &FR);
+            for (uint32_t s = 0; s < d->n_perm_sets; s++) {
+                uint32_t j0 = s * d->chunk_len, j1 = j0 + d->chunk_len > d->n_perm_columns ? d->n_perm_columns : j0 + d->chunk_len;
+                fe left = z[s][r_next], right = z[s][idx];
+                for (uint32_t j = j0; j < j1; j++) {
+                    const fe *col = perm_column(&c, j);
+                    fe_mul(&t, &c.beta, &((const fe *)d->perm_cosets[j])[idx], &FR); fe_add(&t, &t, &col[idx], &FR); fe_add(&t, &t, &c.gamma, &FR);
+                    fe_mul(&left, &left, &t, &FR);
+                }
+                for (uint32_t j = j0; j < j1; j++) {
+                    const fe *col = perm_column(&c, j);
+                    fe_add(&u, &col[idx], &current_delta, &FR); fe_add(&u, &u, &c.gamma, &FR);
+                    fe_mul(&right, &right, &u, &FR);
+                    fe_mul(&current_delta, &current_delta, &delta, &FR);
+                }
+                fe_sub(&t, &left, &right, &FR); fe_mul(&t, &t, &l_active[idx], &FR);
+                fe_mul(value, value, &c.y, &FR); fe_add(value, value, &t, &FR);
+            }
+            fe_mul(&beta_term, &beta_term, &extended_omega, &FR);                                                              /* :439 */
+        }
+    }
+    /* :443-518 lookups */
+    fe *product = (fe *)malloc(size * sizeof(fe)), *pin = (fe *)malloc(size * sizeof(fe)), *ptab = (fe *)malloc(size * sizeof(fe));
+    for (uint32_t n = 0; n < d->n_lookups; n++) {
+        oracle_coeff_to_extended(&dom, (const fe *)d->lookup_product_polys[n], product, 1);
+        oracle_coeff_to_extended(&dom, (const fe *)d->lookup_permuted_input_polys[n], pin, 1);
+        oracle_coeff_to_extended(&dom, (const fe *)d->lookup_permuted_table_polys[n], ptab, 1);
+        const fe zero = {{0, 0, 0, 0}};
+        for (size_t idx = 0; idx < size; idx++) {
+            fe table_value = graph_evaluate(&c, &d->lookup_graphs[n], rotations, inter, &zero, idx);                          /* :466-480 */
+            size_t r_next = get_rotation_idx(idx, 1, c.rot_scale, c.isize), r_prev = get_rotation_idx(idx, -1, c.rot_scale, c.isize);
+            fe *value = &values[idx];
+            fe a_minus_s, t, u, w;
+            fe_sub(&a_minus_s, &pin[idx], &ptab[idx], &FR);
+            /* l_0(X) * (1 - z(X)) = 0 */
+            fe_sub(&t, &one, &product[idx], &FR); fe_mul(&t, &t, &l0[idx], &FR);
+            fe_mul(value, value, &c.y, &FR); fe_add(value, value, &t, &FR);
+            /* l_last(X) * (z(X)^2 - z(X)) = 0 */
+            fe_mul(&t, &product[idx], &product[idx], &FR); fe_sub(&t, &t, &product[idx], &FR); fe_mul(&t, &t, &l_last[idx], &FR);
+            fe_mul(value, value, &c.y, &FR); fe_add(value, value, &t, &FR);
+            /* (1 - (l_last + l_blind)) * (z(wX)(a'+beta)(s'+gamma) - z(X) * table_value) = 0 */
+            fe_add(&t, &pin[idx], &c.beta, &FR); fe_add(&u, &ptab[idx], &c.gamma, &FR);
+            fe_mul(&t, &product[r_next], &t, &FR); fe_mul(&t, &t, &u, &FR);
+            fe_mul(&w, &product[idx], &table_value, &FR); fe_sub(&t, &t, &w, &FR); fe_mul(&t, &t, &l_active[idx], &FR);
+            fe_mul(value, value, &c.y, &FR); fe_add(value, value, &t, &FR);
+            /* l_0(X) * (a'(X) - s'(X)) = 0 */
+            fe_mul(&t, &a_minus_s, &l0[idx], &FR);
+            fe_mul(value, value, &c.y, &FR); fe_add(value, value, &t, &FR);
+            /* (1 - (l_last + l_blind)) * (a' - s') * (a'(X) - a'(w^-1 X)) = 0 */
+            fe_sub(&t, &pin[idx], &pin[r_prev], &FR); fe_mul(&t, &a_minus_s, &t, &FR); fe_mul(&t, &t, &l_active[idx], &FR);
+            fe_mul(value, value, &c.y, &FR); fe_add(value, value, &t, &FR);
+        }
+    }
+    free(product); free(pin); free(ptab); free(rotations); free(inter);
+    for (uint32_t i = 0; i < d->n_advice; i++) free(c.advice[i]);
+    for (uint32_t i = 0; i < d->n_instance; i++) free(c.instance[i]);
+    free(c.advice); free(c.instance);
+    return 0;
+}
