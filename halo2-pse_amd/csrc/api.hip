@@ -322,6 +322,7 @@ void h2hip_shutdown(void) {
     c->host_ws.release();
     c->misc.release();
     c->evalh_ws.release();
+    c->evalh_slots.release();
     (void)hipStreamDestroy(c->stream);
     c->stream = nullptr;
     for (auto e : c->aux_events) (void)hipEventDestroy(e);
@@ -742,9 +743,21 @@ int h2hip_evaluate_h_bn254(const h2hip_evalh_desc* desc, uint64_t* values) {
         set_error("evaluate_h: null argument");
         return H2HIP_EINVAL;
     }
+    if (evaluate_h_validate(desc, values)) return H2HIP_EINVAL;
     Entry en;
     if (en.rc) return en.rc;
-    return evaluate_h_host(en.c, desc, values);
+    return evaluate_h_host(en.c, desc, values, false, en.c->stream);
+}
+
+int h2hip_evaluate_h_bn254_device(const h2hip_evalh_desc* desc, void* d_values, void* stream) {
+    if (!desc || !d_values) {
+        set_error("evaluate_h: null argument");
+        return H2HIP_EINVAL;
+    }
+    if (evaluate_h_validate(desc, d_values)) return H2HIP_EINVAL;
+    Entry en;
+    if (en.rc) return en.rc;
+    return evaluate_h_host(en.c, desc, (uint64_t*)d_values, true, (hipStream_t)stream);
 }
 
 int h2hip_gen_scalars_device(uint64_t seed, uint64_t start, size_t n, void* d_out, void* stream) {
@@ -782,6 +795,17 @@ uint32_t h2hip_get_msm_window(size_t n) { return msm_get_window(n); }
 int h2hip_debug_set_msm_max_chunk(size_t m) {
     msm_set_max_chunk(m);
     return 0;
+}
+
+// test hook: programs needing more slots than v use the global-workspace form of the evaluate_h kernels (default 256)
+int h2hip_debug_set_evalh_max_local_slots(uint32_t v) {
+    evalh_debug_set_max_local_slots(v);
+    return 0;
+}
+
+// test / tuning hook, needs no GPU: compile a graph as evaluate_h would and report the program's size
+int h2hip_debug_evalh_compile_stats(const h2hip_graph* g, uint32_t* n_ops, uint32_t* n_slots) {
+    return evalh_debug_compile_stats(g, n_ops, n_slots);
 }
 
 int h2hip_debug_set_ntt_smax(uint32_t v) {

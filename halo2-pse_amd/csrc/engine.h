@@ -76,7 +76,7 @@ struct Ctx {
     bool ready = false;
     hipStream_t stream = nullptr;  // the engine's own stream (host-pointer entry points)
     std::recursive_mutex mu;       // serialises entry points: re-entrant callers (rayon workers) are safe
-    DevBuf ntt_ws, ntt_io, msm_scalars[3], msm_bases, msm_slot[3], misc, evalh_ws;
+    DevBuf ntt_ws, ntt_io, msm_scalars[3], msm_bases, msm_slot[3], misc, evalh_ws, evalh_slots;
     HostBuf host_ws;               // pinned host memory for the window sums coming back
     std::map<TwiddleKey, TwiddleTable> twiddles;
     std::map<const void*, PinnedBases> pinned;
@@ -119,7 +119,10 @@ int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttSca
 int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const Fe* h_t, uint32_t t_len, hipStream_t s);
 
 // evalh.hip
-int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values);
+void evalh_debug_set_max_local_slots(uint32_t v);
+int evalh_debug_compile_stats(const h2hip_graph* g, uint32_t* n_ops, uint32_t* n_slots);
+int evaluate_h_validate(const h2hip_evalh_desc* d, const void* values);
+int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool dev, hipStream_t s);
 
 // msm.hip
 int msm_device(Ctx* c, const Fe* d_scalars, const Affine* d_bases, size_t n, XYZZ* h_out, hipStream_t s);

@@ -19,14 +19,27 @@
 
 namespace h2 {
 
-#define EVALH_MAX_ROT 64
+#define EVALH_VS_ZERO 11  // internal operand kind: the field's zero (an empty graph's value, evaluation.rs:745-749)
 
-struct GraphDev {
+// The flattened graph is compiled on the host (compile_graph below) into a short register-machine program before it is
+// run: Store calculations become direct column operands, a Horner calculation becomes one FMA per part placed as soon
+// as that part exists, dead calculations are dropped and the surviving intermediates are packed into as few slots as
+// their lifetimes allow.  A slot is 32 B of per-lane scratch (or, past 256 slots, a row of a global workspace), so a
+// circuit with tens of thousands of calculations still runs with a few dozen slots per lane.  The arithmetic performed
+// per row is the reference's, operation for operation; only where a value waits between operations differs.
+enum { OP_ADD = 0, OP_SUB, OP_MUL, OP_SQR, OP_DBL, OP_NEG, OP_MOV, OP_FMA /* dst = dst * y + x */ };
+
+struct DevOp {
+    uint32_t op, dst;
+    h2hip_value_source x, y;  // kind INTERMEDIATE: a = slot
+};
+
+struct ProgDev {
     const Fe* constants;
     const int32_t* rotations;
-    const h2hip_calculation* calcs;
-    const h2hip_value_source* parts;
-    uint32_t n_rot, n_calcs;
+    const DevOp* ops;
+    uint32_t n_ops;
+    h2hip_value_source result;
 };
 
 struct ColsDev {
@@ -39,65 +52,77 @@ struct ColsDev {
     int32_t rot_scale;
 };
 
+// slot storage: MAXI > 0 -> per-lane scratch; MAXI == 0 -> a global workspace laid out [slot][lane] (coalesced per slot)
+template <int MAXI>
+struct Slots {
+    Fe v[MAXI];
+    __device__ __forceinline__ Slots(Fe*, size_t) {}
+    __device__ __forceinline__ Fe get(uint32_t i) const { return v[i]; }
+    __device__ __forceinline__ void set(uint32_t i, const Fe& x) { v[i] = x; }
+};
+template <>
+struct Slots<0> {
+    Fe* base;
+    size_t stride;
+    __device__ __forceinline__ Slots(Fe* b, size_t s) : base(b), stride(s) {}
+    __device__ __forceinline__ Fe get(uint32_t i) const { return base[i * stride]; }
+    __device__ __forceinline__ void set(uint32_t i, const Fe& x) { base[i * stride] = x; }
+};
+
 // get_rotation_idx (evaluation.rs:32-34): size is a power of two, so rem_euclid is a mask
 __device__ __forceinline__ uint32_t rot_idx(uint32_t idx, int32_t rot, int32_t rot_scale, uint32_t log_size) {
     return (uint32_t)((int32_t)idx + rot * rot_scale) & ((1u << log_size) - 1);
 }
 
 // ValueSource::get (evaluation.rs:68-103)
-__device__ __forceinline__ Fe vs_get(const GraphDev& g, const ColsDev& c, const h2hip_value_source& v, const uint32_t* rot, const Fe* inter,
+template <class S>
+__device__ __forceinline__ Fe vs_get(const ProgDev& g, const ColsDev& c, const h2hip_value_source& v, uint32_t idx, const S& slots,
                                      const Fe& previous) {
     switch (v.kind) {
         case H2HIP_VS_CONSTANT: return g.constants[v.a];
-        case H2HIP_VS_INTERMEDIATE: return inter[v.a];
-        case H2HIP_VS_FIXED: return c.fixed[v.a][rot[v.b]];
-        case H2HIP_VS_ADVICE: return c.advice[v.a][rot[v.b]];
-        case H2HIP_VS_INSTANCE: return c.instance[v.a][rot[v.b]];
+        case H2HIP_VS_INTERMEDIATE: return slots.get(v.a);
+        case H2HIP_VS_FIXED: return c.fixed[v.a][rot_idx(idx, g.rotations[v.b], c.rot_scale, c.log_size)];
+        case H2HIP_VS_ADVICE: return c.advice[v.a][rot_idx(idx, g.rotations[v.b], c.rot_scale, c.log_size)];
+        case H2HIP_VS_INSTANCE: return c.instance[v.a][rot_idx(idx, g.rotations[v.b], c.rot_scale, c.log_size)];
         case H2HIP_VS_CHALLENGE: return c.challenges[v.a];
         case H2HIP_VS_BETA: return c.beta;
         case H2HIP_VS_GAMMA: return c.gamma;
         case H2HIP_VS_THETA: return c.theta;
         case H2HIP_VS_Y: return c.y;
-        default: return previous;
+        case H2HIP_VS_PREVIOUS: return previous;
+        default: return fe_zero<FrP>();
     }
 }
 
-// GraphEvaluator::evaluate (evaluation.rs:708-749) with Calculation::evaluate (:129-178)
-template <int MAXI>
-__device__ Fe graph_eval(const GraphDev& g, const ColsDev& c, uint32_t idx, const Fe& previous) {
-    uint32_t rot[EVALH_MAX_ROT];
-    Fe inter[MAXI];
-    for (uint32_t r = 0; r < g.n_rot; r++) rot[r] = rot_idx(idx, g.rotations[r], c.rot_scale, c.log_size);
-    Fe out = fe_zero<FrP>();
-    for (uint32_t q = 0; q < g.n_calcs; q++) {
-        const h2hip_calculation cl = g.calcs[q];
-        Fe a = vs_get(g, c, cl.x, rot, inter, previous);
-        switch (cl.op) {
-            case H2HIP_CALC_ADD: out = fe_add<FrP>(a, vs_get(g, c, cl.y, rot, inter, previous)); break;
-            case H2HIP_CALC_SUB: out = fe_sub<FrP>(a, vs_get(g, c, cl.y, rot, inter, previous)); break;
-            case H2HIP_CALC_MUL: out = fe_mul<FrP>(a, vs_get(g, c, cl.y, rot, inter, previous)); break;
-            case H2HIP_CALC_SQUARE: out = fe_sqr<FrP>(a); break;
-            case H2HIP_CALC_DOUBLE: out = fe_dbl<FrP>(a); break;
-            case H2HIP_CALC_NEGATE: out = fe_neg<FrP>(a); break;
-            case H2HIP_CALC_HORNER: {
-                Fe factor = vs_get(g, c, cl.y, rot, inter, previous);
-                out = a;
-                for (uint32_t t = 0; t < cl.parts_count; t++)
-                    out = fe_add<FrP>(fe_mul<FrP>(out, factor), vs_get(g, c, g.parts[cl.parts_offset + t], rot, inter, previous));
-                break;
-            }
-            default: out = a;  // Store
+// GraphEvaluator::evaluate (evaluation.rs:708-749) with Calculation::evaluate (:129-178), over the compiled program
+template <class S>
+__device__ Fe prog_eval(const ProgDev& g, const ColsDev& c, uint32_t idx, const Fe& previous, S& slots) {
+    for (uint32_t q = 0; q < g.n_ops; q++) {
+        const DevOp o = g.ops[q];
+        const Fe a = vs_get(g, c, o.x, idx, slots, previous);
+        Fe out;
+        switch (o.op) {
+            case OP_ADD: out = fe_add<FrP>(a, vs_get(g, c, o.y, idx, slots, previous)); break;
+            case OP_SUB: out = fe_sub<FrP>(a, vs_get(g, c, o.y, idx, slots, previous)); break;
+            case OP_MUL: out = fe_mul<FrP>(a, vs_get(g, c, o.y, idx, slots, previous)); break;
+            case OP_SQR: out = fe_sqr<FrP>(a); break;
+            case OP_DBL: out = fe_dbl<FrP>(a); break;
+            case OP_NEG: out = fe_neg<FrP>(a); break;
+            case OP_FMA: out = fe_add<FrP>(fe_mul<FrP>(slots.get(o.dst), vs_get(g, c, o.y, idx, slots, previous)), a); break;
+            default: out = a;  // OP_MOV
         }
-        inter[cl.target] = out;
+        slots.set(o.dst, out);
     }
-    return out;  // the last calculation's value, or zero for an empty graph
+    return vs_get(g, c, g.result, idx, slots, previous);
 }
 
+// lanes = threads in the grid; rows beyond it are taken grid-stride (only the global-workspace form launches fewer lanes than rows)
 template <int MAXI>
-__global__ void __launch_bounds__(256) evalh_gates_kernel(GraphDev g, ColsDev c, Fe* values) {
-    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (1u << c.log_size)) return;
-    values[idx] = graph_eval<MAXI>(g, c, idx, values[idx]);
+__global__ void __launch_bounds__(256) evalh_gates_kernel(ProgDev g, ColsDev c, Fe* values, Fe* gws, uint32_t lanes) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= lanes) return;
+    Slots<MAXI> slots(gws + tid, lanes);
+    for (uint64_t idx = tid; idx < (1ull << c.log_size); idx += lanes) values[idx] = prog_eval(g, c, (uint32_t)idx, values[idx], slots);
 }
 
 struct PermDev {
@@ -149,30 +174,34 @@ struct LookupDev {
 };
 
 template <int MAXI>
-__global__ void __launch_bounds__(256) evalh_lookup_kernel(GraphDev g, LookupDev l, ColsDev c, Fe* values) {
-    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (1u << c.log_size)) return;
+__global__ void __launch_bounds__(256) evalh_lookup_kernel(ProgDev g, LookupDev l, ColsDev c, Fe* values, Fe* gws, uint32_t lanes) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= lanes) return;
+    Slots<MAXI> slots(gws + tid, lanes);
     const Fe one = fe_one<FrP>();
-    const Fe table_value = graph_eval<MAXI>(g, c, idx, fe_zero<FrP>());  // :466-480
-    const uint32_t r_next = rot_idx(idx, 1, c.rot_scale, c.log_size), r_prev = rot_idx(idx, -1, c.rot_scale, c.log_size);
-    const Fe z = l.product[idx], a_ = l.pin[idx], s_ = l.ptab[idx];
-    const Fe a_minus_s = fe_sub<FrP>(a_, s_);
-    Fe v = values[idx];
-    // l_0(X) * (1 - z(X)) = 0
-    v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(fe_sub<FrP>(one, z), l.l0[idx]));
-    // l_last(X) * (z(X)^2 - z(X)) = 0
-    v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(fe_sub<FrP>(fe_sqr<FrP>(z), z), l.l_last[idx]));
-    // (1 - (l_last + l_blind)) * (z(wX)(a' + beta)(s' + gamma) - z(X) * table_value) = 0
-    {
-        Fe lhs = fe_mul<FrP>(fe_mul<FrP>(l.product[r_next], fe_add<FrP>(a_, c.beta)), fe_add<FrP>(s_, c.gamma));
-        Fe rhs = fe_mul<FrP>(z, table_value);
-        v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(fe_sub<FrP>(lhs, rhs), l.l_active[idx]));
+    for (uint64_t row = tid; row < (1ull << c.log_size); row += lanes) {
+        const uint32_t idx = (uint32_t)row;
+        const Fe table_value = prog_eval(g, c, idx, fe_zero<FrP>(), slots);  // :466-480
+        const uint32_t r_next = rot_idx(idx, 1, c.rot_scale, c.log_size), r_prev = rot_idx(idx, -1, c.rot_scale, c.log_size);
+        const Fe z = l.product[idx], a_ = l.pin[idx], s_ = l.ptab[idx];
+        const Fe a_minus_s = fe_sub<FrP>(a_, s_);
+        Fe v = values[idx];
+        // l_0(X) * (1 - z(X)) = 0
+        v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(fe_sub<FrP>(one, z), l.l0[idx]));
+        // l_last(X) * (z(X)^2 - z(X)) = 0
+        v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(fe_sub<FrP>(fe_sqr<FrP>(z), z), l.l_last[idx]));
+        // (1 - (l_last + l_blind)) * (z(wX)(a' + beta)(s' + gamma) - z(X) * table_value) = 0
+        {
+            Fe lhs = fe_mul<FrP>(fe_mul<FrP>(l.product[r_next], fe_add<FrP>(a_, c.beta)), fe_add<FrP>(s_, c.gamma));
+            Fe rhs = fe_mul<FrP>(z, table_value);
+            v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(fe_sub<FrP>(lhs, rhs), l.l_active[idx]));
+        }
+        // l_0(X) * (a'(X) - s'(X)) = 0
+        v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(a_minus_s, l.l0[idx]));
+        // (1 - (l_last + l_blind)) * (a' - s') * (a'(X) - a'(w^-1 X)) = 0
+        v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(fe_mul<FrP>(a_minus_s, fe_sub<FrP>(a_, l.pin[r_prev])), l.l_active[idx]));
+        values[idx] = v;
     }
-    // l_0(X) * (a'(X) - s'(X)) = 0
-    v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(a_minus_s, l.l0[idx]));
-    // (1 - (l_last + l_blind)) * (a' - s') * (a'(X) - a'(w^-1 X)) = 0
-    v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(fe_mul<FrP>(a_minus_s, fe_sub<FrP>(a_, l.pin[r_prev])), l.l_active[idx]));
-    values[idx] = v;
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -190,31 +219,149 @@ static bool vs_ok(const h2hip_value_source& v, const h2hip_graph& g, const h2hip
     }
 }
 
-// every index a kernel will dereference is checked here: a malformed graph must be an error, never a GPU fault
+// Every index a kernel will dereference is checked here: a malformed graph must be an error, never a GPU fault.  The
+// graph must also be in the single-assignment form GraphEvaluator builds (add_calculation, evaluation.rs:570-588:
+// every calculation writes a fresh intermediate, operands refer to earlier ones) -- compile_graph relies on it.
 static int graph_validate(const h2hip_graph& g, const h2hip_evalh_desc& d, const char* what) {
-    if (g.num_intermediates > 256 || g.n_rotations > EVALH_MAX_ROT) {
-        set_error("evaluate_h: %s graph too large for this engine (%u intermediates, %u rotations; limits 256, %d)", what, g.num_intermediates,
-                  g.n_rotations, EVALH_MAX_ROT);
-        return 1;
-    }
     if ((g.n_constants && !g.constants) || (g.n_rotations && !g.rotations) || (g.n_calculations && !g.calculations) || (g.n_parts && !g.parts)) {
         set_error("evaluate_h: %s graph has null arrays", what);
         return 1;
     }
+    if (g.num_intermediates > (1u << 24) || g.n_calculations > (1u << 24)) {
+        set_error("evaluate_h: %s graph too large (%u calculations)", what, g.n_calculations);
+        return 1;
+    }
+    std::vector<uint8_t> defined(g.num_intermediates, 0);
+    auto ok_src = [&](const h2hip_value_source& v) { return vs_ok(v, g, d) && (v.kind != H2HIP_VS_INTERMEDIATE || defined[v.a]); };
     for (uint32_t q = 0; q < g.n_calculations; q++) {
         const h2hip_calculation& c = g.calculations[q];
-        bool ok = c.op <= H2HIP_CALC_STORE && c.target < g.num_intermediates && vs_ok(c.x, g, d);
-        if (c.op == H2HIP_CALC_ADD || c.op == H2HIP_CALC_SUB || c.op == H2HIP_CALC_MUL || c.op == H2HIP_CALC_HORNER) ok = ok && vs_ok(c.y, g, d);
+        bool ok = c.op <= H2HIP_CALC_STORE && c.target < g.num_intermediates && !defined[c.target] && ok_src(c.x);
+        if (c.op == H2HIP_CALC_ADD || c.op == H2HIP_CALC_SUB || c.op == H2HIP_CALC_MUL || c.op == H2HIP_CALC_HORNER) ok = ok && ok_src(c.y);
         if (c.op == H2HIP_CALC_HORNER) {
             ok = ok && (uint64_t)c.parts_offset + c.parts_count <= g.n_parts;
-            for (uint32_t t = 0; ok && t < c.parts_count; t++) ok = vs_ok(g.parts[c.parts_offset + t], g, d);
+            for (uint32_t t = 0; ok && t < c.parts_count; t++) ok = ok_src(g.parts[c.parts_offset + t]);
         }
         if (!ok) {
-            set_error("evaluate_h: %s graph, calculation %u is malformed", what, q);
+            set_error("evaluate_h: %s graph, calculation %u is malformed (bad index, or not in single-assignment order)", what, q);
             return 1;
         }
+        defined[c.target] = 1;
     }
     return 0;
+}
+
+// ---- graph -> program (see the comment at DevOp).  Assumes graph_validate passed.
+struct Program {
+    std::vector<DevOp> ops;
+    uint32_t n_slots = 0;
+    h2hip_value_source result = {EVALH_VS_ZERO, 0, 0};
+};
+
+static Program compile_graph(const h2hip_graph& g) {
+    const uint32_t n = g.n_calculations;
+    const h2hip_value_source none = {EVALH_VS_ZERO, 0, 0};
+    Program P;
+    if (n == 0) return P;
+    std::vector<uint32_t> def_of(g.num_intermediates, 0);
+    for (uint32_t q = 0; q < n; q++) def_of[g.calculations[q].target] = q;
+    // a Store is not materialised: whoever reads its target reads its source (ValueSource::get is a pure load)
+    auto resolve = [&](h2hip_value_source v) {
+        while (v.kind == H2HIP_VS_INTERMEDIATE && g.calculations[def_of[v.a]].op == H2HIP_CALC_STORE) v = g.calculations[def_of[v.a]].x;
+        return v;
+    };
+    // 1. emission order; Horner steps are hoisted to the earliest point their part exists.  The value is unchanged:
+    //    ((x*y + p0)*y + p1)... is the same field element whenever each step is executed.
+    struct Hoist { uint32_t q, next; bool started; };
+    std::vector<Hoist> hs;
+    for (uint32_t q = 0; q < n; q++)
+        if (g.calculations[q].op == H2HIP_CALC_HORNER) hs.push_back({q, 0, false});
+    std::vector<DevOp> ops;
+    ops.reserve(n + 16);
+    auto avail = [&](const h2hip_value_source& v, uint32_t q) { return v.kind != H2HIP_VS_INTERMEDIATE || def_of[v.a] <= q; };
+    auto advance = [&](Hoist& h, uint32_t q) {
+        const h2hip_calculation& c = g.calculations[h.q];
+        const h2hip_value_source x = resolve(c.x), y = resolve(c.y);
+        if (!h.started) {
+            if (!avail(x, q) || !avail(y, q)) return;
+            ops.push_back({OP_MOV, c.target, x, none});
+            h.started = true;
+        }
+        while (h.next < c.parts_count) {
+            const h2hip_value_source p = resolve(g.parts[c.parts_offset + h.next]);
+            if (!avail(p, q)) break;
+            ops.push_back({OP_FMA, c.target, p, y});
+            h.next++;
+        }
+    };
+    static const uint32_t op_of[6] = {OP_ADD, OP_SUB, OP_MUL, OP_SQR, OP_DBL, OP_NEG};
+    size_t h_lo = 0;  // Horners before hs[h_lo] are complete
+    for (uint32_t q = 0; q < n; q++) {
+        const h2hip_calculation& c = g.calculations[q];
+        if (c.op <= H2HIP_CALC_NEGATE) {
+            const bool binary = c.op <= H2HIP_CALC_MUL;
+            ops.push_back({op_of[c.op], c.target, resolve(c.x), binary ? resolve(c.y) : none});
+        }
+        while (h_lo < hs.size() && hs[h_lo].q <= q) {
+            if (hs[h_lo].q == q) advance(hs[h_lo], q);  // its own position: everything it reads exists, so this completes it
+            h_lo++;
+        }
+        if (c.op != H2HIP_CALC_STORE || q + 1 == n)
+            for (size_t i = h_lo; i < hs.size() && i < h_lo + 4; i++) advance(hs[i], q);  // look a few Horners ahead (the reference builds 1-2)
+    }
+    h2hip_value_source result = resolve({H2HIP_VS_INTERMEDIATE, g.calculations[n - 1].target, 0});
+    // 2. drop what nothing reads (walking back, every reader of a value is seen before its definition)
+    std::vector<uint8_t> needed(g.num_intermediates, 0);
+    if (result.kind == H2HIP_VS_INTERMEDIATE) needed[result.a] = 1;
+    std::vector<uint8_t> keep(ops.size(), 0);
+    for (size_t i = ops.size(); i-- > 0;) {
+        const DevOp& o = ops[i];
+        if (!needed[o.dst]) continue;
+        keep[i] = 1;
+        if (o.x.kind == H2HIP_VS_INTERMEDIATE) needed[o.x.a] = 1;
+        if (o.y.kind == H2HIP_VS_INTERMEDIATE) needed[o.y.a] = 1;
+    }
+    // 3. lifetimes -> slots.  An operand whose last reader is this op gives its slot to the op's result (operands are
+    //    read into registers before the result is stored).
+    const uint32_t never = 0xffffffffu;
+    std::vector<uint32_t> last_use(g.num_intermediates, 0), slot(g.num_intermediates, never);
+    {
+        uint32_t pos = 0;
+        for (size_t i = 0; i < ops.size(); i++) {
+            if (!keep[i]) continue;
+            const DevOp& o = ops[i];
+            if (o.x.kind == H2HIP_VS_INTERMEDIATE) last_use[o.x.a] = pos;
+            if (o.y.kind == H2HIP_VS_INTERMEDIATE) last_use[o.y.a] = pos;
+            if (o.op == OP_FMA) last_use[o.dst] = pos;
+            pos++;
+        }
+        if (result.kind == H2HIP_VS_INTERMEDIATE) last_use[result.a] = never;
+    }
+    std::vector<uint32_t> free_slots;
+    uint32_t pos = 0;
+    for (size_t i = 0; i < ops.size(); i++) {
+        if (!keep[i]) continue;
+        DevOp o = ops[i];
+        const bool xi = o.x.kind == H2HIP_VS_INTERMEDIATE, yi = o.y.kind == H2HIP_VS_INTERMEDIATE;
+        const uint32_t xv = o.x.a, yv = o.y.a;
+        if (xi) o.x.a = slot[xv];
+        if (yi) o.y.a = slot[yv];
+        if (xi && last_use[xv] == pos) free_slots.push_back(slot[xv]);
+        if (yi && last_use[yv] == pos && !(xi && yv == xv)) free_slots.push_back(slot[yv]);
+        if (slot[o.dst] == never) {  // a definition (FMA steps reuse the slot their MOV took)
+            if (!free_slots.empty()) {
+                slot[o.dst] = free_slots.back();
+                free_slots.pop_back();
+            } else {
+                slot[o.dst] = P.n_slots++;
+            }
+        }
+        o.dst = slot[o.dst];
+        P.ops.push_back(o);
+        pos++;
+    }
+    if (result.kind == H2HIP_VS_INTERMEDIATE) result.a = slot[result.a];
+    P.result = result;
+    return P;
 }
 
 struct Arena {
@@ -227,47 +374,85 @@ struct Arena {
     }
 };
 
-static size_t graph_bytes(const h2hip_graph& g) {
-    return 4 * 256 + g.n_constants * sizeof(Fe) + g.n_rotations * 4 + g.n_calculations * sizeof(h2hip_calculation) + g.n_parts * sizeof(h2hip_value_source);
+static size_t prog_bytes(const h2hip_graph& g, const Program& P) {
+    return 3 * 256 + g.n_constants * sizeof(Fe) + g.n_rotations * 4 + P.ops.size() * sizeof(DevOp);
 }
 
-static int graph_upload(Arena& ar, const h2hip_graph& g, GraphDev* out, hipStream_t s) {
+static int prog_upload(Arena& ar, const h2hip_graph& g, const Program& P, ProgDev* out, hipStream_t s) {
     Fe* dc = (Fe*)ar.take(g.n_constants * sizeof(Fe));
     int32_t* dr = (int32_t*)ar.take(g.n_rotations * 4);
-    h2hip_calculation* dq = (h2hip_calculation*)ar.take(g.n_calculations * sizeof(h2hip_calculation));
-    h2hip_value_source* dp = (h2hip_value_source*)ar.take(g.n_parts * sizeof(h2hip_value_source));
-    if (!dc || !dr || !dq || !dp) {
+    DevOp* dq = (DevOp*)ar.take(P.ops.size() * sizeof(DevOp));
+    if (!dc || !dr || !dq) {
         set_error("evaluate_h: arena overflow");
         return 1;
     }
     if (g.n_constants) H2_CHECK(hipMemcpyAsync(dc, g.constants, g.n_constants * sizeof(Fe), hipMemcpyHostToDevice, s));
     if (g.n_rotations) H2_CHECK(hipMemcpyAsync(dr, g.rotations, g.n_rotations * 4, hipMemcpyHostToDevice, s));
-    if (g.n_calculations) H2_CHECK(hipMemcpyAsync(dq, g.calculations, g.n_calculations * sizeof(h2hip_calculation), hipMemcpyHostToDevice, s));
-    if (g.n_parts) H2_CHECK(hipMemcpyAsync(dp, g.parts, g.n_parts * sizeof(h2hip_value_source), hipMemcpyHostToDevice, s));
+    if (!P.ops.empty()) H2_CHECK(hipMemcpyAsync(dq, P.ops.data(), P.ops.size() * sizeof(DevOp), hipMemcpyHostToDevice, s));
     out->constants = dc;
     out->rotations = dr;
-    out->calcs = dq;
-    out->parts = dp;
-    out->n_rot = g.n_rotations;
-    out->n_calcs = g.n_calculations;
+    out->ops = dq;
+    out->n_ops = (uint32_t)P.ops.size();
+    out->result = P.result;
     return 0;
 }
 
-template <class K32, class K128, class K256>
-static void launch_by_size(uint32_t num_intermediates, K32 k32, K128 k128, K256 k256) {
-    if (num_intermediates <= 32) k32();
-    else if (num_intermediates <= 128) k128();
-    else k256();
+// Where the slots of a program live: per-lane scratch in three sizes, or (past 256) a global workspace of
+// n_slots x lanes elements with the rows taken grid-stride by `lanes` threads.
+struct SlotPlan {
+    int tier;        // 16, 64, 256 or 0 (global)
+    uint32_t lanes;  // threads launched
+    size_t ws_bytes; // global workspace (tier 0)
+};
+
+static uint32_t g_evalh_max_local_slots = 256;  // debug knob (tests force the global-workspace form with it)
+
+static int slot_plan(uint32_t n_slots, size_t size, SlotPlan* out) {
+    const uint32_t all = (uint32_t)((size + 255) / 256 * 256);
+    if (n_slots <= g_evalh_max_local_slots && n_slots <= 256) {
+        out->tier = n_slots <= 16 ? 16 : n_slots <= 64 ? 64 : 256;
+        out->lanes = all;
+        out->ws_bytes = 0;
+        return 0;
+    }
+    uint32_t lanes = all < 256u * 2048u ? all : 256u * 2048u;  // at most every wave slot of the chip
+    const size_t budget = (size_t)32 << 30;
+    while ((size_t)n_slots * lanes * sizeof(Fe) > budget && lanes > 16384) lanes /= 2;
+    if ((size_t)n_slots * lanes * sizeof(Fe) > budget) {
+        set_error("evaluate_h: a graph with %u simultaneously live intermediates does not fit this engine's workspace", n_slots);
+        return H2HIP_ENOMEM;
+    }
+    out->tier = 0;
+    out->lanes = lanes;
+    out->ws_bytes = (size_t)n_slots * lanes * sizeof(Fe);
+    return 0;
 }
 
-int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values) {
+void evalh_debug_set_max_local_slots(uint32_t v) { g_evalh_max_local_slots = v; }
+
+int evalh_debug_compile_stats(const h2hip_graph* g, uint32_t* n_ops, uint32_t* n_slots) {
+    if (!g || !n_ops || !n_slots) {
+        set_error("evaluate_h: null argument");
+        return 1;
+    }
+    h2hip_evalh_desc any;  // column counts are not known here: accept every column index
+    memset(&any, 0, sizeof(any));
+    any.n_fixed = any.n_advice = any.n_instance = any.n_challenges = 0xffffffffu;
+    if (graph_validate(*g, any, "given")) return 1;
+    const Program P = compile_graph(*g);
+    *n_ops = (uint32_t)P.ops.size();
+    *n_slots = P.n_slots;
+    return 0;
+}
+
+// Everything a kernel will dereference is checked here, on the host, before any device work: a malformed description is
+// H2HIP_EINVAL, never a GPU fault.  Needs no device (api.hip calls it before the engine is entered).
+int evaluate_h_validate(const h2hip_evalh_desc* d, const void* values) {
     const uint32_t k = d->k, ek = d->extended_k;
     if (k > ek || ek > 28 || ek - k > 8) {
         set_error("evaluate_h: bad domain (k = %u, extended_k = %u)", k, ek);
         return 1;
     }
-    const size_t n = (size_t)1 << k, size = (size_t)1 << ek;
-    const size_t col_bytes = size * sizeof(Fe);
     if (!d->extended_omega || !d->g_coset || !d->g_coset_inv || !d->y || !d->beta || !d->gamma || !d->theta || !d->l0 || !d->l_last ||
         !d->l_active_row || !values || (d->n_fixed && !d->fixed_cosets) || (d->n_advice && !d->advice_polys) ||
         (d->n_instance && !d->instance_polys) || (d->n_challenges && !d->challenges)) {
@@ -296,25 +481,57 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values) {
             }
         }
     }
+    return 0;
+}
+
+// dev = false: every column pointer in `d` and `values` are host memory (the reference's Vec<F>s); values is updated in place
+//              and the call returns when it is.
+// dev = true:  the columns and `values` are device memory (extended cosets are used where they lie, coefficient-form
+//              polynomials are copied device-to-device before they are extended); the graphs, challenges and scalars stay
+//              host pointers; the kernels are queued on `s` and the call returns without waiting for them.
+int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool dev, hipStream_t s) {
+    const uint32_t k = d->k, ek = d->extended_k;
+    const size_t n = (size_t)1 << k, size = (size_t)1 << ek;
+    const size_t col_bytes = size * sizeof(Fe);
     // ---- device arena
-    const size_t n_cols = (size_t)d->n_fixed + d->n_advice + d->n_instance + 3 /* l0, l_last, l_active */ + d->n_perm_sets + d->n_perm_columns +
-                          3 /* lookup cosets, reused */ + 1 /* values */;
-    size_t need = n_cols * (col_bytes + 256) + 64 * 1024 + graph_bytes(d->custom_gates) + (size_t)d->n_challenges * sizeof(Fe) +
+    const size_t n_cols = dev ? (size_t)d->n_advice + d->n_instance + 3
+                              : (size_t)d->n_fixed + d->n_advice + d->n_instance + 3 /* l0, l_last, l_active */ + d->n_perm_sets + d->n_perm_columns +
+                                    3 /* lookup cosets, reused */ + 1 /* values */;
+    // programs first: their slot counts size the workspaces
+    const Program gates_prog = compile_graph(d->custom_gates);
+    std::vector<Program> lookup_progs(d->n_lookups);
+    for (uint32_t i = 0; i < d->n_lookups; i++) lookup_progs[i] = compile_graph(d->lookup_graphs[i]);
+    int rc;
+    SlotPlan gates_plan;
+    std::vector<SlotPlan> lookup_plans(d->n_lookups);
+    if ((rc = slot_plan(gates_prog.n_slots, size, &gates_plan))) return rc;
+    size_t slots_ws = gates_plan.ws_bytes;
+    for (uint32_t i = 0; i < d->n_lookups; i++) {
+        if ((rc = slot_plan(lookup_progs[i].n_slots, size, &lookup_plans[i]))) return rc;
+        if (lookup_plans[i].ws_bytes > slots_ws) slots_ws = lookup_plans[i].ws_bytes;
+    }
+    size_t need = n_cols * (col_bytes + 256) + 64 * 1024 + prog_bytes(d->custom_gates, gates_prog) + (size_t)d->n_challenges * sizeof(Fe) +
                   8 * ((size_t)d->n_fixed + d->n_advice + d->n_instance + d->n_perm_sets + 2 * (size_t)d->n_perm_columns + 16) + 4096;
-    for (uint32_t i = 0; i < d->n_lookups; i++) need += graph_bytes(d->lookup_graphs[i]);
-    int rc = c->evalh_ws.ensure(need);
-    if (rc) return rc;
-    hipStream_t s = c->stream;
+    for (uint32_t i = 0; i < d->n_lookups; i++) need += prog_bytes(d->lookup_graphs[i], lookup_progs[i]);
+    if ((rc = c->evalh_ws.ensure(need))) return rc;
+    if (slots_ws && (rc = c->evalh_slots.ensure(slots_ws))) return rc;
+    Fe* const gws = (Fe*)c->evalh_slots.p;
+    if ((rc = c->ws_acquire(s))) return rc;
+    const hipMemcpyKind in_kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     Arena ar;
     ar.base = (char*)c->evalh_ws.p;
     ar.cap = c->evalh_ws.cap;
     auto col_upload = [&](const uint64_t* h, size_t elems, Fe** out) -> int {
+        if (dev && elems == size && h) {  // an extended coset already in HBM: used where it lies
+            *out = (Fe*)h;
+            return 0;
+        }
         Fe* p = (Fe*)ar.take(col_bytes);
         if (!p || !h) {
             set_error("evaluate_h: null column or arena overflow");
             return 1;
         }
-        H2_CHECK(hipMemcpyAsync(p, h, elems * sizeof(Fe), hipMemcpyHostToDevice, s));
+        H2_CHECK(hipMemcpyAsync(p, h, elems * sizeof(Fe), in_kind, s));
         *out = p;
         return 0;
     };
@@ -371,12 +588,17 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values) {
     const dim3 grid((uint32_t)((size + 255) / 256)), block(256);
 
     // ---- custom gates (:334-360)
-    GraphDev gd;
-    if ((rc = graph_upload(ar, d->custom_gates, &gd, s))) return rc;
-    launch_by_size(
-        d->custom_gates.num_intermediates, [&] { hipLaunchKernelGGL(evalh_gates_kernel<32>, grid, block, 0, s, gd, cols, d_values); },
-        [&] { hipLaunchKernelGGL(evalh_gates_kernel<128>, grid, block, 0, s, gd, cols, d_values); },
-        [&] { hipLaunchKernelGGL(evalh_gates_kernel<256>, grid, block, 0, s, gd, cols, d_values); });
+    ProgDev gd;
+    if ((rc = prog_upload(ar, d->custom_gates, gates_prog, &gd, s))) return rc;
+    {
+        const dim3 g(gates_plan.lanes / 256);
+        switch (gates_plan.tier) {
+            case 16: hipLaunchKernelGGL(evalh_gates_kernel<16>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes); break;
+            case 64: hipLaunchKernelGGL(evalh_gates_kernel<64>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes); break;
+            case 256: hipLaunchKernelGGL(evalh_gates_kernel<256>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes); break;
+            default: hipLaunchKernelGGL(evalh_gates_kernel<0>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes);
+        }
+    }
     H2_CHECK(hipGetLastError());
 
     // ---- permutations (:362-441)
@@ -420,19 +642,25 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values) {
                     set_error("evaluate_h: null lookup polynomial");
                     return 1;
                 }
-                H2_CHECK(hipMemcpyAsync(buf[t], polys[t], n * sizeof(Fe), hipMemcpyHostToDevice, s));
+                H2_CHECK(hipMemcpyAsync(buf[t], polys[t], n * sizeof(Fe), in_kind, s));
                 if ((rc = ntt_device(c, buf[t], ext_omega, ek, &sc, s))) return rc;
             }
-            GraphDev lg;
-            if ((rc = graph_upload(ar, d->lookup_graphs[i], &lg, s))) return rc;
+            ProgDev lg;
+            if ((rc = prog_upload(ar, d->lookup_graphs[i], lookup_progs[i], &lg, s))) return rc;
             LookupDev ld = {buf[0], buf[1], buf[2], l0, l_last, l_active};
-            launch_by_size(
-                d->lookup_graphs[i].num_intermediates, [&] { hipLaunchKernelGGL(evalh_lookup_kernel<32>, grid, block, 0, s, lg, ld, cols, d_values); },
-                [&] { hipLaunchKernelGGL(evalh_lookup_kernel<128>, grid, block, 0, s, lg, ld, cols, d_values); },
-                [&] { hipLaunchKernelGGL(evalh_lookup_kernel<256>, grid, block, 0, s, lg, ld, cols, d_values); });
+            const SlotPlan& lp = lookup_plans[i];
+            const dim3 g(lp.lanes / 256);
+            switch (lp.tier) {
+                case 16: hipLaunchKernelGGL(evalh_lookup_kernel<16>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
+                case 64: hipLaunchKernelGGL(evalh_lookup_kernel<64>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
+                case 256: hipLaunchKernelGGL(evalh_lookup_kernel<256>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
+                default: hipLaunchKernelGGL(evalh_lookup_kernel<0>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes);
+            }
             H2_CHECK(hipGetLastError());
         }
     }
+    if ((rc = c->ws_release(s))) return rc;
+    if (dev) return 0;
     H2_CHECK(hipMemcpyAsync(values, d_values, col_bytes, hipMemcpyDeviceToHost, s));
     H2_CHECK(hipStreamSynchronize(s));
     return 0;

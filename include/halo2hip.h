@@ -213,8 +213,15 @@ typedef struct {
     const uint64_t* const* lookup_permuted_table_polys;
 } h2hip_evalh_desc;
 
-/* values: 2^extended_k elements, in/out, host memory */
+/* values: 2^extended_k elements, in/out, host memory; every column pointer in desc is host memory */
 int h2hip_evaluate_h_bn254(const h2hip_evalh_desc* desc, uint64_t* values);
+/* Device-resident form for a prover whose columns already live in HBM: every column pointer in desc (fixed_cosets[i],
+ * advice_polys[i], instance_polys[i], l0 / l_last / l_active_row, perm_product_cosets[i], perm_cosets[j], the lookup
+ * polynomials) and d_values are device pointers; extended cosets are read where they lie, coefficient-form polynomials
+ * are copied device-to-device before they are extended, so no input is modified.  The pointer tables themselves,
+ * the graphs, challenges and scalars stay host memory.  Kernels are queued on `stream` (NULL = the default stream);
+ * the call does not wait for them. */
+int h2hip_evaluate_h_bn254_device(const h2hip_evalh_desc* desc, void* d_values, void* stream);
 
 /* ---- synthetic workload; same streams as oracle_gen_{scalars,points} ---- */
 

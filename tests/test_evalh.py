@@ -124,3 +124,181 @@ def test_gpu_evaluate_h_vs_oracle(h2, oracle, k):
     rc = h2.lib().h2hip_evaluate_h_bn254(h.byref(), got.ctypes.data_as(ctypes.c_void_p))
     assert rc == 0, h2.lib().h2hip_last_error()
     assert np.array_equal(got, want)
+
+
+def test_evaluate_h_rejects_malformed_descriptions(h2, oracle, evalh_golden):
+    """a description a kernel could fault on is H2HIP_EINVAL before any device work (no GPU needed): an intermediate
+    beyond num_intermediates, a column beyond n_advice, a Horner part range past the parts array, a graph that is
+    not in single-assignment order, a permutation column out of range, too few permutation sets"""
+    import copy
+    L = h2.lib()
+    case, vin, _ = load_case(evalh_golden, "k3")
+
+    def rc_of(mutate):
+        c = copy.deepcopy(case)
+        mutate(c)
+        h = DescHolder(c)
+        v = vin.copy()
+        return L.h2hip_evaluate_h_bn254(h.byref(), v.ctypes.data_as(ctypes.c_void_p))
+
+    def bad_target(c): c["custom"]["calcs"][0, 1] = 10_000
+    def bad_column(c): c["custom"]["calcs"][0, 3] = 99          # x.a of the first Store: advice column 99
+    def bad_rotation(c): c["custom"]["calcs"][0, 4] = 99        # x.b: rotation index
+    def bad_parts(c): c["custom"]["calcs"][-1, 9] = 1000        # Horner parts_count
+    def bad_op(c): c["custom"]["calcs"][0, 0] = 8
+    def rewritten_target(c): c["custom"]["calcs"][1, 1] = c["custom"]["calcs"][0, 1]   # not single-assignment
+    def read_before_write(c): c["custom"]["calcs"][0, 2:5] = (1, c["custom"]["calcs"][-1, 1], 0)  # x = a later intermediate
+    def bad_perm_col(c): c["perm_column_index"] = np.array([0, 1, 77], dtype=np.uint32)
+    def few_sets(c): c["chunk_len"] = 1
+    def bad_domain(c): c["extended_k"] = 2
+    def bad_lookup(c): c["lookups"][0][0]["calcs"][0, 3] = 99
+
+    for m in (bad_target, bad_column, bad_rotation, bad_parts, bad_op, rewritten_target, read_before_write, bad_perm_col, few_sets, bad_domain, bad_lookup):
+        assert rc_of(m) == 1, m.__name__
+        assert b"evaluate_h" in L.h2hip_last_error()
+    assert L.h2hip_evaluate_h_bn254(None, None) == 1
+
+
+def test_evaluator_new_builds_the_golden_graphs(evalh_golden):
+    """Evaluator.new over the circuit-layout gate polynomials reproduces the graphs stored with the golden vectors"""
+    from evalh_util import Evaluator, flatten_graph
+    A = lambda col, rot=0: ('advice', col, rot)  # noqa: E731
+    F = lambda col, rot=0: ('fixed', col, rot)  # noqa: E731
+    e_, a_, b_, c_, d_ = 0, 1, 2, 3, 4
+    sf, sm, sa, sb, sc, sl = 0, 1, 2, 3, 4, 5
+    gate = ('sum',
+            ('sum', ('sum', ('sum', ('prod', A(a_), F(sa)), ('prod', A(b_), F(sb))), ('prod', ('prod', A(a_), A(b_)), F(sm))),
+             ('neg', ('prod', A(c_), F(sc)))),
+            ('prod', F(sf), ('prod', A(d_, 1), A(e_, -1))))
+    gate2 = ('sum', ('scaled', ('prod', A(c_), A(c_)), 7), ('sum', ('prod', ('const', 2), A(d_)), ('neg', ('const', 5))))
+    ev = Evaluator.new([gate, gate2], [([A(a_)], [F(sl)])])
+    for name, g in (("custom", ev.custom_gates), ("lookup0", ev.lookups[0])):
+        f = flatten_graph(g)
+        for key in ("constants", "rotations", "calcs", "parts"):
+            assert np.array_equal(f[key], evalh_golden["k3_" + name + "_" + key]), (name, key)
+
+
+@pytest.mark.gpu
+def test_gpu_evaluate_h_device_resident(h2, oracle):
+    """h2hip_evaluate_h_bn254_device: every column already in HBM (torch tensors), values folded in place on the current
+    stream, inputs untouched; equal to the oracle and to the host-pointer entry point"""
+    import torch
+    case, vin = _random_case(oracle, 11, seed=77)
+    h = DescHolder(case)
+    want = vin.copy()
+    assert oracle.lib().oracle_evaluate_h(h.byref(), want.ctypes.data_as(ctypes.c_void_p)) == 0
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()  # noqa: E731
+    keep = []
+    tens = {}
+    for key in ("fixed_cosets", "advice_polys", "instance_polys", "perm_product_cosets", "perm_cosets"):
+        tens[key] = [dev(a) for a in case[key]]
+    for key in ("l0", "l_last", "l_active_row"):
+        tens[key] = dev(case[key])
+    tens["lookups"] = [[dev(p) for p in l[1:]] for l in case["lookups"]]
+    before = {k: ([t.clone() for t in v] if isinstance(v, list) and not isinstance(v[0], list) else v) for k, v in tens.items() if k != "lookups"}
+    hd = DescHolder(case)  # host description first, then swap in the device addresses
+    d = hd.desc
+
+    def table(ts):
+        arr = (ctypes.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts])
+        keep.append(arr)
+        return ctypes.addressof(arr)
+
+    d.fixed_cosets, d.advice_polys, d.instance_polys = table(tens["fixed_cosets"]), table(tens["advice_polys"]), table(tens["instance_polys"])
+    d.perm_product_cosets, d.perm_cosets = table(tens["perm_product_cosets"]), table(tens["perm_cosets"])
+    d.l0, d.l_last, d.l_active_row = tens["l0"].data_ptr(), tens["l_last"].data_ptr(), tens["l_active_row"].data_ptr()
+    d.lookup_product_polys = table([l[0] for l in tens["lookups"]])
+    d.lookup_permuted_input_polys = table([l[1] for l in tens["lookups"]])
+    d.lookup_permuted_table_polys = table([l[2] for l in tens["lookups"]])
+    d_values = dev(vin)
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = h2.lib().h2hip_evaluate_h_bn254_device(hd.byref(), ctypes.c_void_p(d_values.data_ptr()), ctypes.c_void_p(stream))
+    assert rc == 0, h2.lib().h2hip_last_error()
+    torch.cuda.synchronize()
+    got = d_values.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want)
+    for key in ("fixed_cosets", "advice_polys", "instance_polys", "perm_product_cosets", "perm_cosets"):
+        for t0, t1 in zip(before[key], tens[key]):
+            assert torch.equal(t0, t1), key  # inputs are read-only
+
+
+def _compile_stats(h2, graph_dict):
+    """(n_ops, n_slots) of the program evaluate_h compiles a flattened graph into (host-only debug entry point)"""
+    from evalh_util import DescHolder as DH
+    holder = DH.__new__(DH)
+    holder.keep = []
+    G = holder._graph(graph_dict)
+    n_ops, n_slots = ctypes.c_uint32(), ctypes.c_uint32()
+    rc = h2.lib().h2hip_debug_evalh_compile_stats(ctypes.byref(G), ctypes.byref(n_ops), ctypes.byref(n_slots))
+    assert rc == 0, h2.lib().h2hip_last_error()
+    return n_ops.value, n_slots.value
+
+
+def _many_live_graph(n_live):
+    """a hand-made single-assignment graph whose n_live products are all alive at once: they are consumed in reverse
+    order of creation, so no slot can be reused before the last product exists"""
+    from evalh_util import CALC_ADD, CALC_HORNER, CALC_MUL, GraphEvaluator, VS_ADVICE, VS_FIXED, VS_PREVIOUS, VS_Y
+    g = GraphEvaluator()
+    r0, r1 = g.add_rotation(0), g.add_rotation(1)
+    prods = [g.add_calculation((CALC_MUL, (VS_ADVICE, i % 5, r0 if i % 2 else r1), (VS_FIXED, i % 6, r0), ())) for i in range(n_live)]
+    # distinct coefficients keep add_calculation from deduplicating: t_i = p_i * const_i
+    terms = [g.add_calculation((CALC_MUL, p, g.add_constant(1000 + i), ())) for i, p in enumerate(prods)]
+    acc = terms[-1]
+    for t in reversed(terms[:-1]):
+        acc = g.add_calculation((CALC_ADD, acc, t, ()))
+    g.add_calculation((CALC_HORNER, (VS_PREVIOUS, 0, 0), (VS_Y, 0, 0), (acc,)))
+    return g
+
+
+def test_compiled_program_is_compact(h2, oracle):
+    """Stores are folded into operands, the Horner is spread over its parts, and intermediates share slots: the
+    three-gate system needs a handful of slots; the reversed-consumption graph needs one per live product"""
+    from evalh_util import flatten_graph
+    case, _ = _random_case(oracle, 5, seed=5, n_gates=40)
+    g = case["custom"]
+    assert g["num_intermediates"] > 256
+    n_ops, n_slots = _compile_stats(h2, g)
+    assert n_slots <= 32 and n_ops <= g["calcs"].shape[0] + g["parts"].shape[0] + 1
+    n_ops, n_slots = _compile_stats(h2, flatten_graph(_many_live_graph(300)))
+    assert 300 <= n_slots <= 302
+    assert _compile_stats(h2, {"constants": np.zeros((0, 4), np.uint64), "rotations": np.zeros(0, np.int32),
+                               "calcs": np.zeros((0, 10), np.uint32), "parts": np.zeros((0, 3), np.uint32), "num_intermediates": 0}) == (0, 0)
+
+
+@pytest.mark.gpu
+def test_gpu_evaluate_h_large_graph(h2, oracle):
+    """more intermediates than any per-lane scratch tier holds one-to-one (the reference's Vec is unbounded): slots are
+    shared by lifetime"""
+    case, vin = _random_case(oracle, 8, seed=21, n_gates=40)
+    assert case["custom"]["num_intermediates"] > 256
+    h = DescHolder(case)
+    want = vin.copy()
+    assert oracle.lib().oracle_evaluate_h(h.byref(), want.ctypes.data_as(ctypes.c_void_p)) == 0
+    got = vin.copy()
+    assert h2.lib().h2hip_evaluate_h_bn254(h.byref(), got.ctypes.data_as(ctypes.c_void_p)) == 0, h2.lib().h2hip_last_error()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("forced", [False, True])
+def test_gpu_evaluate_h_global_slot_workspace(h2, oracle, forced):
+    """programs whose live values exceed 256 slots run from a global workspace with rows taken grid-stride; `forced`
+    pushes every program of an ordinary system through that form with the debug knob, the other case gets there by
+    itself with 300 simultaneously live products"""
+    from evalh_util import flatten_graph
+    L = h2.lib()
+    case, vin = _random_case(oracle, 9, seed=33)
+    if not forced:
+        case["custom"] = flatten_graph(_many_live_graph(300))
+    h = DescHolder(case)
+    want = vin.copy()
+    assert oracle.lib().oracle_evaluate_h(h.byref(), want.ctypes.data_as(ctypes.c_void_p)) == 0
+    got = vin.copy()
+    try:
+        if forced:
+            L.h2hip_debug_set_evalh_max_local_slots(0)
+        rc = L.h2hip_evaluate_h_bn254(h.byref(), got.ctypes.data_as(ctypes.c_void_p))
+    finally:
+        L.h2hip_debug_set_evalh_max_local_slots(256)
+    assert rc == 0, L.h2hip_last_error()
+    assert np.array_equal(got, want)
