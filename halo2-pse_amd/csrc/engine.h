@@ -114,7 +114,9 @@ struct NttScale {
     bool out_scale = false;   // a[i] *= out3[i % 3] on the final-pass store
     Fe out3[3];
 };
-int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttScale* sc, hipStream_t s);
+// d_src (optional): the first pass reads its input there instead of d_data (which is then output only); with
+// sc->in_len set only d_src[0 .. in_len) is read
+int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttScale* sc, hipStream_t s, const Fe* d_src = nullptr);
 
 int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const Fe* h_t, uint32_t t_len, hipStream_t s);
 

@@ -130,7 +130,8 @@ struct PermDev {
     const Fe* const* cols;    // the permuted columns' extended cosets, already resolved by (kind, index)
     const Fe* const* cosets;  // pk.permutation.cosets
     const Fe *l0, *l_last, *l_active;
-    Fe extended_omega, delta, delta_start;  // delta_start = beta * ZETA (:368)
+    Fe delta, delta_start;  // delta_start = beta * ZETA (:368)
+    const Fe* omega_pow2;   // [28] extended_omega^(2^j): extended_omega^idx is a product over the set bits of idx
     uint32_t n_sets, n_cols, chunk_len;
     int32_t last_rotation;
 };
@@ -153,7 +154,9 @@ __global__ void __launch_bounds__(256) evalh_perm_kernel(PermDev p, ColsDev c, F
     for (uint32_t s = 1; s < p.n_sets; s++)
         v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(fe_sub<FrP>(p.z[s][idx], p.z[s - 1][r_last]), p.l0[idx]));
     // (1 - (l_last + l_blind)) * (z_i(wX) prod(p + beta s_j + gamma) - z_i(X) prod(p + delta^j beta X + gamma))   :405-438
-    Fe current_delta = fe_mul<FrP>(p.delta_start, fe_pow_u64<FrP>(p.extended_omega, idx));  // beta_term = extended_omega^idx
+    Fe current_delta = p.delta_start;  // beta * ZETA * extended_omega^idx (beta_term, :366-368 and :412)
+    for (uint32_t j = 0; j < c.log_size; j++)
+        if ((idx >> j) & 1) current_delta = fe_mul<FrP>(current_delta, p.omega_pow2[j]);
     for (uint32_t s = 0; s < p.n_sets; s++) {
         const uint32_t j0 = s * p.chunk_len, j1 = j0 + p.chunk_len < p.n_cols ? j0 + p.chunk_len : p.n_cols;
         Fe left = p.z[s][r_next], right = p.z[s][idx];
@@ -545,9 +548,17 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         sc.in_len = n;
     }
     auto poly_to_coset = [&](const uint64_t* h, Fe** out) -> int {
-        int r = col_upload(h, n, out);
-        if (r) return r;
-        return ntt_device(c, *out, ext_omega, ek, &sc, s);
+        if (!dev) {
+            int r = col_upload(h, n, out);
+            return r ? r : ntt_device(c, *out, ext_omega, ek, &sc, s);
+        }
+        Fe* p = (Fe*)ar.take(col_bytes);  // device-resident coefficients: the first NTT pass reads them where they lie
+        if (!p || !h) {
+            set_error("evaluate_h: null column or arena overflow");
+            return 1;
+        }
+        *out = p;
+        return ntt_device(c, p, ext_omega, ek, &sc, s, (const Fe*)h);
     };
     std::vector<const Fe*> fixed(d->n_fixed), advice(d->n_advice), instance(d->n_instance);
     Fe* tmp;
@@ -616,7 +627,18 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         pd.l0 = l0;
         pd.l_last = l_last;
         pd.l_active = l_active;
-        pd.extended_omega = ext_omega;
+        {
+            Fe pw[28];
+            pw[0] = ext_omega;
+            for (int j = 1; j < 28; j++) pw[j] = fe_sqr<FrP>(pw[j - 1]);
+            Fe* d_pw = (Fe*)ar.take(sizeof(pw));
+            if (!d_pw) {
+                set_error("evaluate_h: arena overflow");
+                return 1;
+            }
+            H2_CHECK(hipMemcpyAsync(d_pw, pw, sizeof(pw), hipMemcpyHostToDevice, s));
+            pd.omega_pow2 = d_pw;
+        }
         pd.delta = *(const Fe*)d->delta;
         pd.delta_start = fe_mul<FrP>(cols.beta, *(const Fe*)d->zeta);
         pd.n_sets = d->n_perm_sets;
@@ -642,8 +664,8 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
                     set_error("evaluate_h: null lookup polynomial");
                     return 1;
                 }
-                H2_CHECK(hipMemcpyAsync(buf[t], polys[t], n * sizeof(Fe), in_kind, s));
-                if ((rc = ntt_device(c, buf[t], ext_omega, ek, &sc, s))) return rc;
+                if (!dev) H2_CHECK(hipMemcpyAsync(buf[t], polys[t], n * sizeof(Fe), hipMemcpyHostToDevice, s));
+                if ((rc = ntt_device(c, buf[t], ext_omega, ek, &sc, s, dev ? (const Fe*)polys[t] : nullptr))) return rc;
             }
             ProgDev lg;
             if ((rc = prog_upload(ar, d->lookup_graphs[i], lookup_progs[i], &lg, s))) return rc;

@@ -282,7 +282,8 @@ static int plan_passes(uint32_t log_n, uint32_t s_out[4]) {
     return P;
 }
 
-int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttScale* sc, hipStream_t s) {
+int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttScale* sc, hipStream_t s, const Fe* d_src) {
+    const Fe* const first_src = d_src ? d_src : d_data;
     if (log_n > FrP::S) {
         set_error("ntt: log_n=%u exceeds the 2-adicity of Fr (28)", log_n);
         return 1;
@@ -304,7 +305,7 @@ int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttSca
     if (rc0) return rc0;
     int tid = c->timer_begin("ntt", s);
     if (log_n == 0) {
-        p.src = d_data;
+        p.src = first_src;
         p.dst = d_data;
         p.first = 1;
         hipLaunchKernelGGL(ntt_n1_kernel, dim3(1), dim3(64), 0, s, p);
@@ -333,7 +334,7 @@ int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttSca
         p.first = (t == 0);
         bool final = (t == P - 1);
         if (final) {
-            p.src = (P == 1) ? d_data : ws;
+            p.src = (P == 1) ? first_src : ws;
             p.dst = d_data;
             uint32_t log_nb = log_n - p.s;
             const uint32_t want_j = p.s <= 8 ? 2 : 1;  // 4 columns (128 B rows) up to 256-point tiles, 2 beyond: LDS
@@ -342,7 +343,7 @@ int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttSca
             for (int q = 0; q < P - 1; q++) p.prev_s[q] = S[q];
         } else {
             bool to_ws = (t == P - 2);  // last strided pass goes out of place so the final pass lands in d_data
-            p.src = d_data;
+            p.src = t == 0 ? first_src : d_data;  // passes own disjoint tiles: reading elsewhere than they write is safe
             p.dst = to_ws ? ws : d_data;
             uint32_t log_l = log_m - p.s;
             const uint32_t want_j = p.s <= 8 ? 2 : 1;

@@ -2,7 +2,9 @@
  * oracle/bn254_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
  *
  * CPU restatement (plain C, gcc, unsigned __int128) of the halo2_proofs hot
- * path: BN254 G1 multi-scalar multiplication and the radix-2 NTT over BN254 Fr.
+ * path: BN254 G1 multi-scalar multiplication, the radix-2 NTT over BN254 Fr with
+ * the EvaluationDomain conversions around it, and Evaluator::evaluate_h
+ * (plonk/evaluation.rs:280-522, at the end of this file).
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
  * this file's shared object; the product (libhalo2hip.so) never does.
  *
@@ -12,7 +14,9 @@
  * and its own tests hold no BN254 byte-level vectors (they draw the SRS from
  * OsRng: poly/kzg/commitment.rs:365,381).  This restatement is therefore pinned
  * by (i) independent Python big-integer golden vectors (tests/golden/, made by
- * tests/golden/make_golden.py: naive affine double-and-add MSM, O(n^2) DFT) and
+ * tests/golden/make_golden.py: naive affine double-and-add MSM, O(n^2) DFT;
+ * tests/golden/make_evalh_golden.py: the gate / permutation / lookup constraint
+ * formulas evaluated row by row, not through the flattened graph) and
  * (ii) the algebraic identities the reference's tests assert
  * (test_commit_lagrange, poly/kzg/commitment.rs:361-384).
  *
