@@ -714,7 +714,7 @@ int h2hip_divide_by_vanishing_poly_bn254_fr_device(void* d_a, uint32_t extended_
         if (check_fr(t_evaluations + 4 * i, "t_evaluations[i]")) return H2HIP_EINVAL;
     Entry en;
     if (en.rc) return en.rc;
-    return scale_periodic_device(en.c, (Fe*)d_a, 1ull << extended_k, (const Fe*)t_evaluations, t_len, (hipStream_t)stream);
+    return scale_periodic_device(en.c, (Fe*)d_a, 1ull << extended_k, t_evaluations, t_len, (hipStream_t)stream);
 }
 
 int h2hip_divide_by_vanishing_poly_bn254_fr(uint64_t* a, uint32_t extended_k, const uint64_t* t_evaluations, uint32_t t_len) {
@@ -731,7 +731,7 @@ int h2hip_divide_by_vanishing_poly_bn254_fr(uint64_t* a, uint32_t extended_k, co
     int rc = c->ntt_io.ensure(bytes);
     if (rc) return rc;
     H2_CHECK(hipMemcpyAsync(c->ntt_io.p, a, bytes, hipMemcpyHostToDevice, c->stream));
-    rc = scale_periodic_device(c, (Fe*)c->ntt_io.p, 1ull << extended_k, (const Fe*)t_evaluations, t_len, c->stream);
+    rc = scale_periodic_device(c, (Fe*)c->ntt_io.p, 1ull << extended_k, t_evaluations, t_len, c->stream);
     if (rc) return rc;
     H2_CHECK(hipMemcpyAsync(a, c->ntt_io.p, bytes, hipMemcpyDeviceToHost, c->stream));
     H2_CHECK(hipStreamSynchronize(c->stream));

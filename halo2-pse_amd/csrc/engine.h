@@ -118,7 +118,7 @@ struct NttScale {
 // sc->in_len set only d_src[0 .. in_len) is read
 int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttScale* sc, hipStream_t s, const Fe* d_src = nullptr);
 
-int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const Fe* h_t, uint32_t t_len, hipStream_t s);
+int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const uint64_t* h_t, uint32_t t_len, hipStream_t s);
 
 // evalh.hip
 void evalh_debug_set_max_local_slots(uint32_t v);

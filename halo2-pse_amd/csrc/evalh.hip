@@ -209,6 +209,13 @@ __global__ void __launch_bounds__(256) evalh_lookup_kernel(ProgDev g, LookupDev 
 
 // ---------------------------------------------------------------------------------------------- host side
 
+// caller memory is only 8-byte aligned (4 x u64); Fe is alignas(16)
+static inline Fe load_fe(const uint64_t* v) {
+    Fe o;
+    memcpy(o.l, v, sizeof(o.l));
+    return o;
+}
+
 static bool vs_ok(const h2hip_value_source& v, const h2hip_graph& g, const h2hip_evalh_desc& d) {
     switch (v.kind) {
         case H2HIP_VS_CONSTANT: return v.a < g.n_constants;
@@ -538,13 +545,13 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         *out = p;
         return 0;
     };
-    const Fe ext_omega = *(const Fe*)d->extended_omega;
+    const Fe ext_omega = load_fe(d->extended_omega);
     NttScale sc;
     {   // distribute_powers_zeta(into_coset) + zero-pad + NTT, as h2hip_coeff_to_extended does
         sc.in_scale = true;
         sc.in3[0] = fe_one<FrP>();
-        sc.in3[1] = *(const Fe*)d->g_coset;
-        sc.in3[2] = *(const Fe*)d->g_coset_inv;
+        sc.in3[1] = load_fe(d->g_coset);
+        sc.in3[2] = load_fe(d->g_coset_inv);
         sc.in_len = n;
     }
     auto poly_to_coset = [&](const uint64_t* h, Fe** out) -> int {
@@ -590,10 +597,10 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         if (d->n_challenges) H2_CHECK(hipMemcpyAsync(dch, d->challenges, d->n_challenges * sizeof(Fe), hipMemcpyHostToDevice, s));
         cols.challenges = dch;
     }
-    cols.beta = *(const Fe*)d->beta;
-    cols.gamma = *(const Fe*)d->gamma;
-    cols.theta = *(const Fe*)d->theta;
-    cols.y = *(const Fe*)d->y;
+    cols.beta = load_fe(d->beta);
+    cols.gamma = load_fe(d->gamma);
+    cols.theta = load_fe(d->theta);
+    cols.y = load_fe(d->y);
     cols.log_size = ek;
     cols.rot_scale = 1 << (ek - k);
     const dim3 grid((uint32_t)((size + 255) / 256)), block(256);
@@ -639,8 +646,8 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
             H2_CHECK(hipMemcpyAsync(d_pw, pw, sizeof(pw), hipMemcpyHostToDevice, s));
             pd.omega_pow2 = d_pw;
         }
-        pd.delta = *(const Fe*)d->delta;
-        pd.delta_start = fe_mul<FrP>(cols.beta, *(const Fe*)d->zeta);
+        pd.delta = load_fe(d->delta);
+        pd.delta_start = fe_mul<FrP>(cols.beta, load_fe(d->zeta));
         pd.n_sets = d->n_perm_sets;
         pd.n_cols = d->n_perm_columns;
         pd.chunk_len = d->chunk_len;

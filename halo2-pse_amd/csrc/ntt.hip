@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256) scale_periodic_kernel(Fe* a, uint64_t n, 
         a[i] = fu_mul_canon<FrU>(fu_slice(a[i]), t_i[i % t_len]);
 }
 
-int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const Fe* h_t, uint32_t t_len, hipStream_t s) {
+int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const uint64_t* h_t, uint32_t t_len, hipStream_t s) {
     if (t_len == 0 || t_len > 4096) {
         set_error("divide_by_vanishing_poly: t_len %u out of range", t_len);
         return 1;
@@ -254,7 +254,11 @@ int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const Fe* h_t, uint32_t t
     rc = c->misc.ensure((size_t)t_len * sizeof(Fu));
     if (rc) return rc;
     std::vector<Fu> t(t_len);
-    for (uint32_t i = 0; i < t_len; i++) t[i] = fu_i_from_fe(h_t[i]);
+    for (uint32_t i = 0; i < t_len; i++) {
+        Fe e;  // caller memory is only 8-byte aligned
+        memcpy(e.l, h_t + 4 * (size_t)i, sizeof(e.l));
+        t[i] = fu_i_from_fe(e);
+    }
     H2_CHECK(hipMemcpyAsync(c->misc.p, t.data(), (size_t)t_len * sizeof(Fu), hipMemcpyHostToDevice, s));
     H2_CHECK(hipStreamSynchronize(s));  // t lives on this stack frame
     uint64_t blocks = (n + 255) / 256;

@@ -7,6 +7,7 @@
 //   halo2_proofs::arithmetic::best_fft           halo2_proofs/src/arithmetic.rs:171-234
 //   halo2_proofs::poly::EvaluationDomain         halo2_proofs/src/poly/domain.rs:18-361
 //   halo2_proofs::poly::kzg::ParamsKZG           halo2_proofs/src/poly/kzg/commitment.rs:22-339
+//   halo2_proofs::plonk::{GraphEvaluator, Evaluator}   halo2_proofs/src/plonk/evaluation.rs   (in evaluation.hpp)
 //
 // Error behaviour: where the reference panics on a contract violation (assert_eq! / assert!),
 // this mirror throws std::logic_error; a non-zero engine status throws std::runtime_error
@@ -42,7 +43,9 @@ struct Fr {
     Fr pow_vartime(uint64_t e) const { return from_fe(h2::fe_pow_u64<h2::FrP>(fe(), e)); }
     static Fr root_of_unity() { return from_limbs32(h2::FrP::ROOT_OF_UNITY); }
     static Fr zeta() { return from_limbs32(h2::FrP::ZETA); }
+    static Fr delta() { return from(7).pow_vartime(uint64_t(1) << S_); }  // Fr::DELTA = MULTIPLICATIVE_GENERATOR^(2^S)
     static constexpr uint32_t S = 28;
+    static constexpr uint32_t S_ = 28;
     h2::Fe fe() const {
         h2::Fe f;
         std::memcpy(f.l, l, 32);

@@ -5,6 +5,7 @@
 #include <fstream>
 #include <string>
 
+#include "../../halo2-pse_amd/host/evaluation.hpp"
 #include "../../halo2-pse_amd/host/halo2hip.hpp"
 
 using namespace halo2_proofs;
@@ -87,7 +88,108 @@ static void test_contract_violations() {
     CHECK(panics([&] { domain.lagrange_to_coeff(p); }));
 }
 
+// ---- plonk::Evaluator (halo2-pse_amd/host/evaluation.hpp)
+using namespace halo2_proofs::plonk;
+
+// the constraint system of examples/circuit-layout.rs MyCircuit (:174-240) as tests/golden/make_evalh_golden.py states it
+static void circuit_layout_system(std::vector<Expr>* gates, std::vector<LookupArgument>* lookups) {
+    const uint32_t e_ = 0, a_ = 1, b_ = 2, c_ = 3, d_ = 4, sf = 0, sm = 1, sa = 2, sb = 3, sc = 4, sl = 5;
+    auto A = [](uint32_t c, int32_t r = 0) { return Expression::advice(c, r); };
+    auto F = [](uint32_t c, int32_t r = 0) { return Expression::fixed(c, r); };
+    Expr gate = A(a_) * F(sa) + A(b_) * F(sb) + A(a_) * A(b_) * F(sm) - (A(c_) * F(sc)) + F(sf) * (A(d_, 1) * A(e_, -1));
+    Expr gate2 = (A(c_) * A(c_)) * Fr::from(7) + (Expression::constant(Fr::from(2)) * A(d_) + (-Expression::constant(Fr::from(5))));
+    *gates = {gate, gate2};
+    *lookups = {LookupArgument{{A(a_)}, {F(sl)}}};
+}
+
+static void dump_graph(std::FILE* f, const char* name, const GraphEvaluator& g) {
+    FlatGraph fg = g.flatten();
+    std::fprintf(f, "%s num_intermediates %u\n", name, fg.num_intermediates);
+    for (auto& c : fg.constants) std::fprintf(f, "%s constant %llu %llu %llu %llu\n", name, (unsigned long long)c.l[0], (unsigned long long)c.l[1],
+                                              (unsigned long long)c.l[2], (unsigned long long)c.l[3]);
+    for (auto r : fg.rotations) std::fprintf(f, "%s rotation %d\n", name, r);
+    for (auto& c : fg.calculations)
+        std::fprintf(f, "%s calc %u %u %u %u %u %u %u %u %u %u\n", name, c.op, c.target, c.x.kind, c.x.a, c.x.b, c.y.kind, c.y.a, c.y.b, c.parts_offset,
+                     c.parts_count);
+    for (auto& p : fg.parts) std::fprintf(f, "%s part %u %u %u\n", name, p.kind, p.a, p.b);
+}
+
+static int dump_graphs(const char* path) {
+    std::vector<Expr> gates;
+    std::vector<LookupArgument> lookups;
+    circuit_layout_system(&gates, &lookups);
+    Evaluator ev = Evaluator::create(gates, lookups);
+    std::FILE* f = std::fopen(path, "w");
+    if (!f) return 2;
+    dump_graph(f, "custom", ev.custom_gates);
+    dump_graph(f, "lookup0", ev.lookups[0]);
+    std::fclose(f);
+    return 0;
+}
+
+// Expression::evaluate (plonk/circuit.rs) at one row of the extended domain, for the check below
+static Fr eval_expr(const Expr& e, const std::vector<std::vector<Fr>>& fixed, const std::vector<std::vector<Fr>>& advice, size_t idx, int rot_scale) {
+    const size_t size = fixed[0].size();
+    auto at = [&](const std::vector<Fr>& col, int32_t rot) { return col[(idx + size + (long)rot * rot_scale) % size]; };
+    switch (e->kind) {
+        case Expression::Constant: return e->scalar;
+        case Expression::Fixed: return at(fixed[e->index], e->rotation);
+        case Expression::Advice: return at(advice[e->index], e->rotation);
+        case Expression::Negated: return Fr::zero() - eval_expr(e->a, fixed, advice, idx, rot_scale);
+        case Expression::Sum: return eval_expr(e->a, fixed, advice, idx, rot_scale) + eval_expr(e->b, fixed, advice, idx, rot_scale);
+        case Expression::Product: return eval_expr(e->a, fixed, advice, idx, rot_scale) * eval_expr(e->b, fixed, advice, idx, rot_scale);
+        case Expression::Scaled: return eval_expr(e->a, fixed, advice, idx, rot_scale) * e->scalar;
+        default: throw std::logic_error("not used here");
+    }
+}
+
+// custom gates of the circuit-layout system through Evaluator::evaluate_h == the Expression trees evaluated row by row
+// on the cosets (no permutation, no lookups here: tests/test_evalh.py covers those against the oracle)
+static void test_evaluate_h_custom_gates() {
+    const uint32_t k = 5;
+    EvaluationDomain domain(4, k);
+    const size_t n = size_t(1) << k, size = domain.extended_len();
+    std::vector<Expr> gates;
+    std::vector<LookupArgument> lookups;
+    circuit_layout_system(&gates, &lookups);
+    Evaluator ev = Evaluator::create(gates, {});
+    Fr x = Fr::from(3);
+    auto next = [&] {
+        x = x * x + Fr::from(11);
+        return x;
+    };
+    std::vector<std::vector<Fr>> fixed(6, std::vector<Fr>(size)), advice_polys(5, std::vector<Fr>(n)), advice_cosets;
+    for (auto& c : fixed)
+        for (auto& v : c) v = next();
+    for (auto& c : advice_polys)
+        for (auto& v : c) v = next();
+    for (auto& c : advice_polys) advice_cosets.push_back(domain.coeff_to_extended(Polynomial<Coeff>{c}).values);
+    std::vector<Fr> l0(size), l_last(size), l_active(size), values(size);
+    for (auto& v : values) v = next();
+    EvaluateHInputs in;
+    in.domain = &domain;
+    for (auto& c : fixed) in.fixed_cosets.push_back(&c);
+    for (auto& c : advice_polys) in.advice_polys.push_back(&c);
+    in.y = next();
+    in.beta = next();
+    in.gamma = next();
+    in.theta = next();
+    in.l0 = &l0;
+    in.l_last = &l_last;
+    in.l_active_row = &l_active;
+    std::vector<Fr> want = values;
+    const int rot_scale = 1 << (domain.extended_k - k);
+    for (size_t idx = 0; idx < size; idx++)
+        for (auto& g : gates) want[idx] = want[idx] * in.y + eval_expr(g, fixed, advice_cosets, idx, rot_scale);
+    ev.evaluate_h(in, values);
+    CHECK(values == want);
+    // a polynomial of the wrong length is a contract violation
+    std::vector<Fr> short_values(size / 2);
+    CHECK(panics([&] { ev.evaluate_h(in, short_values); }));
+}
+
 int main(int argc, char** argv) {
+    if (argc > 2 && std::string(argv[1]) == "--dump-graphs") return dump_graphs(argv[2]);
     std::string dir = argc > 1 ? argv[1] : "tests/golden";
     if (h2hip_init(nullptr, 0) != 0) {
         std::printf("h2hip_init failed: %s\n", h2hip_last_error());
@@ -96,6 +198,7 @@ int main(int argc, char** argv) {
     test_commit_lagrange(dir);
     test_domain_roundtrips();
     test_contract_violations();
+    test_evaluate_h_custom_gates();
     h2hip_shutdown();
     std::printf(failures ? "HOST MIRROR TESTS FAILED (%d)\n" : "host mirror tests ok\n", failures);
     return failures ? 1 : 0;

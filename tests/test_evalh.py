@@ -104,6 +104,13 @@ def _random_case(oracle, k, seed, n_gates=3):
 @pytest.mark.parametrize("tag", ["k3", "k4"])
 def test_gpu_evaluate_h_golden(h2, oracle, evalh_golden, tag):
     case, vin, vout = load_case(evalh_golden, tag)
+    if tag == "k4":  # scalars at addresses that are only 8-byte aligned, as inside a Rust struct
+        for f in ("extended_omega", "g_coset", "g_coset_inv", "zeta", "delta", "y", "beta", "gamma", "theta"):
+            buf = np.zeros(7, dtype=np.uint64)
+            off = 1 if buf.ctypes.data % 16 == 0 else 2
+            buf[off:off + 4] = case[f]
+            case[f] = buf[off:off + 4]
+            assert case[f].ctypes.data % 16 == 8
     h = DescHolder(case)
     values = vin.copy()
     rc = h2.lib().h2hip_evaluate_h_bn254(h.byref(), values.ctypes.data_as(ctypes.c_void_p))
@@ -302,3 +309,27 @@ def test_gpu_evaluate_h_global_slot_workspace(h2, oracle, forced):
         L.h2hip_debug_set_evalh_max_local_slots(256)
     assert rc == 0, L.h2hip_last_error()
     assert np.array_equal(got, want)
+
+
+def test_cpp_graph_evaluator_matches_golden_graphs(evalh_golden, tmp_path):
+    """halo2-pse_amd/host/evaluation.hpp (C++ mirror of GraphEvaluator / Evaluator::new): the circuit-layout system built
+    with the C++ Expression operators flattens to the graphs stored with the golden vectors (host only)"""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "cpp", "test_host_mirror")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = tmp_path / "graphs.txt"
+    r = subprocess.run([exe, "--dump-graphs", str(out)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = {}
+    for line in out.read_text().splitlines():
+        name, kind, *vals = line.split()
+        got.setdefault((name, kind), []).append([int(v) for v in vals])
+    for name in ("custom", "lookup0"):
+        p = "k3_" + name + "_"
+        assert got[(name, "num_intermediates")] == [[int(evalh_golden[p + "num_intermediates"][0])]]
+        assert np.array_equal(np.array(got[(name, "constant")], dtype=np.uint64), evalh_golden[p + "constants"])
+        assert np.array_equal(np.array(got[(name, "rotation")], dtype=np.int32).reshape(-1), evalh_golden[p + "rotations"])
+        assert np.array_equal(np.array(got[(name, "calc")], dtype=np.uint32), evalh_golden[p + "calcs"])
+        assert np.array_equal(np.array(got.get((name, "part"), []), dtype=np.uint32).reshape(-1, 3), evalh_golden[p + "parts"])
