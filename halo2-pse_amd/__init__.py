@@ -132,6 +132,15 @@ def best_fft(a, omega, log_n):
     _check(lib().h2hip_ntt_bn254_fr(_p(a), _p(_fe(omega)), ctypes.c_uint32(log_n)), "h2hip_ntt_bn254_fr")
 
 
+def g_to_lagrange(g, k):
+    """arithmetic::g_to_lagrange (arithmetic.rs:277-301): (2^k, 8) affine points -> (2^k, 8) affine points"""
+    g = _u64(g, 8)
+    assert g.shape[0] == 1 << k
+    out = np.zeros((1 << k, 8), dtype=np.uint64)
+    _check(lib().h2hip_g_to_lagrange_bn254(_p(g), ctypes.c_uint32(k), _p(out)), "h2hip_g_to_lagrange_bn254")
+    return out
+
+
 def g1_to_affine(xyz):
     xyz = np.ascontiguousarray(xyz, dtype=np.uint64).reshape(12)
     out = np.zeros(8, dtype=np.uint64)
@@ -217,10 +226,11 @@ class ParamsKZG:
     are pinned on the GPU for the life of the object; commit / commit_lagrange are
     best_multiexp over them (:281-292, :327-334; the blind is ignored there too)."""
 
-    def __init__(self, k, g, g_lagrange):
+    def __init__(self, k, g, g_lagrange=None):
+        """g_lagrange None: derived from g with g_to_lagrange, as downsize does (:274)"""
         self.k, self.n = int(k), 1 << int(k)
         self.g = _u64(g, 8).copy()
-        self.g_lagrange = _u64(g_lagrange, 8).copy()
+        self.g_lagrange = g_to_lagrange(self.g, self.k) if g_lagrange is None else _u64(g_lagrange, 8).copy()
         assert self.g.shape[0] == self.n and self.g_lagrange.shape[0] == self.n
         bases_pin(self.g)
         bases_pin(self.g_lagrange)
@@ -244,6 +254,16 @@ class ParamsKZG:
         out = np.zeros(12, dtype=np.uint64)
         _check(lib().h2hip_msm_bn254(_p(poly), _p(self.g), ctypes.c_size_t(size), _p(out)), "h2hip_msm_bn254")
         return out
+
+    def downsize(self, k):
+        """ParamsKZG::downsize (poly/kzg/commitment.rs:267-275)"""
+        assert k <= self.k  # :268
+        self.close()
+        self.k, self.n = int(k), 1 << int(k)
+        self.g = self.g[:self.n].copy()                       # self.g.truncate(self.n)
+        self.g_lagrange = g_to_lagrange(self.g, self.k)       # :274
+        bases_pin(self.g)
+        bases_pin(self.g_lagrange)
 
     def close(self):
         for b in (self.g, self.g_lagrange):

@@ -323,6 +323,7 @@ void h2hip_shutdown(void) {
     c->misc.release();
     c->evalh_ws.release();
     c->evalh_slots.release();
+    c->ecfft_ws.release();
     (void)hipStreamDestroy(c->stream);
     c->stream = nullptr;
     for (auto e : c->aux_events) (void)hipEventDestroy(e);
@@ -734,6 +735,37 @@ int h2hip_divide_by_vanishing_poly_bn254_fr(uint64_t* a, uint32_t extended_k, co
     rc = scale_periodic_device(c, (Fe*)c->ntt_io.p, 1ull << extended_k, t_evaluations, t_len, c->stream);
     if (rc) return rc;
     H2_CHECK(hipMemcpyAsync(a, c->ntt_io.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    H2_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int h2hip_g_to_lagrange_bn254_device(const void* d_g_xy, uint32_t k, void* d_g_lagrange_xy, void* stream) {
+    if (!d_g_xy || !d_g_lagrange_xy || k > 28) {
+        set_error("g_to_lagrange: bad argument");
+        return H2HIP_EINVAL;
+    }
+    Entry en;
+    if (en.rc) return en.rc;
+    return g_to_lagrange_device(en.c, (const Affine*)d_g_xy, k, (Affine*)d_g_lagrange_xy, (hipStream_t)stream);
+}
+
+int h2hip_g_to_lagrange_bn254(const uint64_t* g_xy, uint32_t k, uint64_t* g_lagrange_xy) {
+    if (!g_xy || !g_lagrange_xy || k > 28) {
+        set_error("g_to_lagrange: bad argument");
+        return H2HIP_EINVAL;
+    }
+    Entry en;
+    if (en.rc) return en.rc;
+    Ctx* c = en.c;
+    const size_t bytes = sizeof(Affine) << k;
+    int rc = c->ntt_io.ensure(2 * bytes);
+    if (rc) return rc;
+    Affine* d_in = (Affine*)c->ntt_io.p;
+    Affine* d_out = (Affine*)((char*)c->ntt_io.p + bytes);
+    if ((rc = c->ws_acquire(c->stream))) return rc;
+    H2_CHECK(hipMemcpyAsync(d_in, g_xy, bytes, hipMemcpyHostToDevice, c->stream));
+    if ((rc = g_to_lagrange_device(c, d_in, k, d_out, c->stream))) return rc;
+    H2_CHECK(hipMemcpyAsync(g_lagrange_xy, d_out, bytes, hipMemcpyDeviceToHost, c->stream));
     H2_CHECK(hipStreamSynchronize(c->stream));
     return 0;
 }

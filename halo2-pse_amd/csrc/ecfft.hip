@@ -1,0 +1,175 @@
+// ecfft.hip -- g_to_lagrange (halo2_proofs/src/arithmetic.rs:277-301): best_fft with G = bn256::G1 over the SRS points,
+// then the 1/n scale and batch_normalize.  Called by ParamsKZG::downsize (poly/kzg/commitment.rs:267-275).
+//
+// The butterfly of a curve-point FFT is t = [w] b; (a, b) <- (a + t, a - t): one 254-bit scalar multiplication per
+// butterfly, k/2 * n of them -- VALU work, a few hundred bytes per butterfly.  One lane per butterfly; layers follow
+// the reference's iterative form (arithmetic.rs:202-230: bit-reversal, then chunks 2, 4, ... n with
+// twiddles[i * twiddle_chunk]).  Between layers the points are brought back to affine by a batched inversion so that
+// every addition inside the scalar ladder is a mixed addition (9.2 vs 14 multiplications):
+//   ecfft_layer_kernel      t = [w] b by MSB-first double-and-add in the unsaturated XYZZ arithmetic of ecu.cuh (the
+//                           MSM's), the two closing additions in canonical ec.cuh arithmetic; layer 0 applies the
+//                           bit-reversal on its loads; butterflies with w = 1 skip the ladder (arithmetic.rs:255-260)
+//   ec_normalize_kernel     XYZZ -> affine, Montgomery's trick over 8 points per lane
+//   ec_scale_kernel         [n_inv] p for every point (wave-uniform scalar: no divergence), arithmetic.rs:286-290
+// Only the group elements are defined by the reference (its Jacobian coordinates depend on the butterfly order); the
+// affine output is canonical, so it is compared limb for limb.
+#include <string.h>
+
+#include "engine.h"
+
+namespace h2 {
+
+struct Scalar256 {
+    uint32_t w[8];  // canonical integer, little-endian
+};
+
+// acc = [e] p for an affine p (E-form), e a canonical 254-bit integer
+__device__ XYZZu ec_mul_affine(const Affine& p, const Scalar256& e) {
+    XYZZu acc = xyzzu_identity();
+    if (affine_is_identity(p)) return acc;
+    const Fu px = fu_from_ext(p.x), py = fu_from_ext(p.y);
+    for (int i = 253; i >= 0; i--) {
+        acc = xyzzu_double(acc);
+        if ((e.w[i >> 5] >> (i & 31)) & 1) xyzzu_add_mixed<QU>(acc, px, py);
+    }
+    return acc;
+}
+
+struct EcfftLayer {
+    const Affine* in;
+    XYZZ* out;
+    const Scalar256* tw;  // omega_inv^i, i < n / 2
+    uint32_t log_n, s;    // layer s: half = 2^s
+};
+
+__global__ void __launch_bounds__(256) ecfft_layer_kernel(EcfftLayer L) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n = 1ull << L.log_n;
+    if (tid >= n / 2) return;
+    const uint64_t half = 1ull << L.s;
+    const uint64_t i = tid & (half - 1), blk = tid >> L.s;
+    const uint64_t ia = (blk << (L.s + 1)) + i, ib = ia + half;
+    uint64_t la = ia, lb = ib;
+    if (L.s == 0) {  // best_fft's swap loop (arithmetic.rs:186-191), folded into the first layer's loads
+        la = __brevll(ia) >> (64 - L.log_n);
+        lb = __brevll(ib) >> (64 - L.log_n);
+    }
+    const Affine a = L.in[la], b = L.in[lb];
+    XYZZ t;
+    if (i == 0) {
+        t = xyzz_from_affine(b);  // twiddle one
+    } else {
+        const Scalar256 w = L.tw[i << (L.log_n - 1 - L.s)];  // twiddles[i * twiddle_chunk], twiddle_chunk = n / 2^(s+1)
+        t = xyzzu_to_ext(ec_mul_affine(b, w));
+    }
+    XYZZ hi = t, lo = t;
+    lo.y = fe_neg<FqP>(t.y);
+    xyzz_add_mixed(hi, a);  // a + t
+    xyzz_add_mixed(lo, a);  // a - t
+    L.out[ia] = hi;
+    L.out[ib] = lo;
+}
+
+__global__ void __launch_bounds__(256) ec_scale_kernel(const Affine* in, XYZZ* out, uint64_t n, Scalar256 e) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n) return;
+    out[tid] = xyzzu_to_ext(ec_mul_affine(in[tid], e));
+}
+
+#define EC_NORM_CHUNK 8
+// lane t normalises points t, t + L, t + 2L, ... (L = lanes): one inversion per EC_NORM_CHUNK points
+__global__ void __launch_bounds__(256) ec_normalize_kernel(const XYZZ* in, Affine* out, uint64_t n, uint64_t lanes) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= lanes) return;
+    Fe prefix[EC_NORM_CHUNK];
+    Fe acc = fe_one<FqP>();
+#pragma unroll
+    for (int j = 0; j < EC_NORM_CHUNK; j++) {
+        const uint64_t idx = tid + (uint64_t)j * lanes;
+        prefix[j] = acc;
+        if (idx < n) {
+            const Fe zzz = in[idx].zzz;
+            if (!fe_is_zero(zzz)) acc = fe_mul<FqP>(acc, zzz);
+        }
+    }
+    Fe inv = fe_inv<FqP>(acc);
+#pragma unroll
+    for (int j = EC_NORM_CHUNK - 1; j >= 0; j--) {
+        const uint64_t idx = tid + (uint64_t)j * lanes;
+        if (idx >= n) continue;
+        const XYZZ p = in[idx];
+        Affine o;
+        if (fe_is_zero(p.zzz)) {  // identity (zz == 0 <=> zzz == 0): (0, 0)
+            o.x = fe_zero<FqP>();
+            o.y = fe_zero<FqP>();
+        } else {
+            const Fe zzz_inv = fe_mul<FqP>(inv, prefix[j]);  // 1 / Z^3
+            inv = fe_mul<FqP>(inv, p.zzz);
+            const Fe zz_inv = fe_mul<FqP>(fe_sqr<FqP>(zzz_inv), fe_sqr<FqP>(p.zz));  // Z^-6 * Z^4
+            o.x = fe_mul<FqP>(p.x, zz_inv);
+            o.y = fe_mul<FqP>(p.y, zzz_inv);
+        }
+        out[idx] = o;
+    }
+}
+
+__global__ void __launch_bounds__(256) ecfft_twiddle_kernel(Scalar256* tw, uint64_t count, Fe omega_inv) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= count) return;
+    const Fe c = fe_to_canonical<FrP>(fe_pow_u64<FrP>(omega_inv, tid));
+    Scalar256 o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.w[i] = c.l[i];
+    tw[tid] = o;
+}
+
+static int normalize_launch(const XYZZ* in, Affine* out, uint64_t n, hipStream_t s) {
+    const uint64_t lanes = (n + EC_NORM_CHUNK - 1) / EC_NORM_CHUNK;
+    hipLaunchKernelGGL(ec_normalize_kernel, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, s, in, out, n, lanes);
+    H2_CHECK(hipGetLastError());
+    return 0;
+}
+
+// d_g: n affine points in (read only); d_out: n affine points out.  Queued on s; does not wait.
+int g_to_lagrange_device(Ctx* c, const Affine* d_g, uint32_t k, Affine* d_out, hipStream_t s) {
+    if (k > FrP::S) {
+        set_error("g_to_lagrange: k = %u exceeds the 2-adicity of Fr", k);
+        return 1;
+    }
+    const uint64_t n = 1ull << k;
+    // workspace: XYZZ[n] | twiddles[n / 2]; the affine points of the current layer live in d_out
+    const size_t xyzz_bytes = n * sizeof(XYZZ), tw_bytes = (n / 2 + 1) * sizeof(Scalar256);
+    int rc = c->ecfft_ws.ensure(xyzz_bytes + tw_bytes + 256);
+    if (rc) return rc;
+    if ((rc = c->ws_acquire(s))) return rc;
+    XYZZ* d_xyzz = (XYZZ*)c->ecfft_ws.p;
+    Scalar256* d_tw = (Scalar256*)((char*)c->ecfft_ws.p + ((xyzz_bytes + 255) / 256) * 256);
+    int tid = c->timer_begin("g_to_lagrange", s);
+    // arithmetic.rs:278-282
+    Fe omega_inv;
+    memcpy(omega_inv.l, FrP::ROOT_OF_UNITY_INV, sizeof(omega_inv.l));  // Montgomery form, as stored
+    for (uint32_t i = k; i < FrP::S; i++) omega_inv = fe_sqr<FrP>(omega_inv);
+    const Fe two_inv = fe_inv<FrP>(fe_from_u64<FrP>(2));
+    const Fe n_inv = fe_to_canonical<FrP>(fe_pow_u64<FrP>(two_inv, k));
+    Scalar256 e_ninv;
+    for (int i = 0; i < 8; i++) e_ninv.w[i] = n_inv.l[i];
+    if (n >= 2) {
+        hipLaunchKernelGGL(ecfft_twiddle_kernel, dim3((uint32_t)((n / 2 + 255) / 256)), dim3(256), 0, s, d_tw, n / 2, omega_inv);
+        H2_CHECK(hipGetLastError());
+    }
+    const Affine* src = d_g;
+    for (uint32_t layer = 0; layer < k; layer++) {
+        EcfftLayer L = {src, d_xyzz, d_tw, k, layer};
+        hipLaunchKernelGGL(ecfft_layer_kernel, dim3((uint32_t)((n / 2 + 255) / 256)), dim3(256), 0, s, L);
+        H2_CHECK(hipGetLastError());
+        if ((rc = normalize_launch(d_xyzz, d_out, n, s))) return rc;
+        src = d_out;
+    }
+    hipLaunchKernelGGL(ec_scale_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, src, d_xyzz, n, e_ninv);
+    H2_CHECK(hipGetLastError());
+    if ((rc = normalize_launch(d_xyzz, d_out, n, s))) return rc;
+    c->timer_end(tid, s);
+    return c->ws_release(s);
+}
+
+}  // namespace h2

@@ -76,7 +76,7 @@ struct Ctx {
     bool ready = false;
     hipStream_t stream = nullptr;  // the engine's own stream (host-pointer entry points)
     std::recursive_mutex mu;       // serialises entry points: re-entrant callers (rayon workers) are safe
-    DevBuf ntt_ws, ntt_io, msm_scalars[3], msm_bases, msm_slot[3], misc, evalh_ws, evalh_slots;
+    DevBuf ntt_ws, ntt_io, msm_scalars[3], msm_bases, msm_slot[3], misc, evalh_ws, evalh_slots, ecfft_ws;
     HostBuf host_ws;               // pinned host memory for the window sums coming back
     std::map<TwiddleKey, TwiddleTable> twiddles;
     std::map<const void*, PinnedBases> pinned;
@@ -119,6 +119,9 @@ struct NttScale {
 int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttScale* sc, hipStream_t s, const Fe* d_src = nullptr);
 
 int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const uint64_t* h_t, uint32_t t_len, hipStream_t s);
+
+// ecfft.hip
+int g_to_lagrange_device(Ctx* c, const Affine* d_g, uint32_t k, Affine* d_out, hipStream_t s);
 
 // evalh.hip
 void evalh_debug_set_max_local_slots(uint32_t v);

@@ -106,6 +106,13 @@ inline void best_fft(std::vector<Fr>& a, const Fr& omega, uint32_t log_n) {
     engine_check(h2hip_ntt_bn254_fr(a[0].l, omega.l, log_n), "best_fft");
 }
 
+// g_to_lagrange (arithmetic.rs:277-301); takes the affine points (the reference converts them with to_curve() at the call site)
+inline std::vector<G1Affine> g_to_lagrange(const std::vector<G1Affine>& g, uint32_t k) {
+    if (g.size() != (size_t(1) << k)) throw std::logic_error("assertion failed: a.len() == 1 << log_n");  // best_fft, :184
+    std::vector<G1Affine> out(g.size());
+    engine_check(h2hip_g_to_lagrange_bn254(g[0].x, k, out[0].x), "h2hip_g_to_lagrange_bn254");
+    return out;
+}
 }  // namespace arithmetic
 
 namespace poly {
@@ -243,8 +250,16 @@ class ParamsKZG {
         p.pin();
     }
 
-    // downsize (poly/kzg/commitment.rs:267-275) needs g_to_lagrange, a curve-point FFT that is not on the
-    // accelerated path: only the truncation half is mirrored; callers re-read g_lagrange for the new k.
+    // downsize (poly/kzg/commitment.rs:267-275)
+    void downsize(uint32_t k_) {
+        if (k_ > k) throw std::logic_error("assertion failed: k <= self.k");  // :268
+        unpin();
+        k = k_;
+        n = uint64_t(1) << k;
+        g.resize(n);                                                          // truncate, :273
+        g_lagrange = arithmetic::g_to_lagrange(g, k);                         // :274
+        pin();
+    }
 
     // commit_lagrange (poly/kzg/commitment.rs:281-292); the blind is ignored there too
     G1 commit_lagrange(const Polynomial<LagrangeCoeff>& poly, const Blind&) const {

@@ -139,6 +139,12 @@ int h2hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream)
 int h2hip_memset_zero(void* d_dst, size_t bytes, void* stream);
 int h2hip_stream_synchronize(void* stream);
 
+/* ---- g_to_lagrange: arithmetic.rs:277-301 (best_fft with G = G1, then 1/n and batch_normalize); called by
+ * ParamsKZG::downsize, poly/kzg/commitment.rs:267-275.  g_xy: 2^k affine points (the coefficient-basis SRS, possibly
+ * truncated); g_lagrange_xy: 2^k affine points out.  k <= 28.  Input and output may not overlap. */
+int h2hip_g_to_lagrange_bn254(const uint64_t* g_xy, uint32_t k, uint64_t* g_lagrange_xy);
+int h2hip_g_to_lagrange_bn254_device(const void* d_g_xy, uint32_t k, void* d_g_lagrange_xy, void* stream);
+
 /* ---- Evaluator::evaluate_h: plonk/evaluation.rs:280-522 ---------------------------------------
  * The quotient numerator h(X) on the extended coset: per row, the custom-gate graph (GraphEvaluator, :191-201,
  * :708-749), the permutation argument's constraints (:362-441) and every lookup's constraints (:443-518), folded

@@ -823,6 +823,90 @@ int oracle_kzg_commit(const fe *poly, size_t size, const g1a *bases, size_t base
     return oracle_best_multiexp(poly, bases, size, num_threads, out);
 }
 
+/* ------------------------------------------------------------------ g_to_lagrange: best_fft over G = G1 */
+/* Group for G1 (halo2curves): group_add / group_sub are point addition / subtraction, group_scale multiplies by an
+ * Fr scalar.  Points stay Jacobian between layers, as C::Curve does in the reference. */
+static void g1j_neg(g1j *o, const g1j *p) { *o = *p; fe_neg(&o->y, &p->y, &FQ); }
+
+static void g1_butterfly_layer(g1j *left, g1j *right, size_t half, size_t twiddle_chunk, const fe *tw) {
+    /* arithmetic.rs:209-226 / :255-272 with G = G1: i = 0 has twiddle one */
+    for (size_t i = 0; i < half; i++) {
+        g1j t = right[i], nt;
+        if (i) {
+            uint64_t e[4];
+            fe_to_canonical(e, &tw[i * twiddle_chunk], &FR);
+            g1j_mul_canonical(&t, &right[i], e);                        /* t.group_scale(&twiddles[..]) */
+        }
+        g1j_neg(&nt, &t);
+        g1j_add(&right[i], &left[i], &nt);                              /* b = a - t */
+        g1j_add(&left[i], &left[i], &t);                                /* a = a + t */
+    }
+}
+
+typedef struct { g1j *a; size_t n, lo, hi, chunk, twiddle_chunk; const fe *tw; } g1_layer_job;
+static void *g1_layer_thread(void *arg) {
+    g1_layer_job *j = (g1_layer_job *)arg;
+    for (size_t b = j->lo; b < j->hi; b += j->chunk)
+        g1_butterfly_layer(j->a + b, j->a + b + j->chunk / 2, j->chunk / 2, j->twiddle_chunk, j->tw);
+    return NULL;
+}
+
+/* g_to_lagrange (arithmetic.rs:277-301): inverse FFT of the coefficient-basis SRS points, scaled by 1/n, normalised.
+ * The butterflies are those of best_fft's iterative form (arithmetic.rs:202-230); its recursive form (:232) performs the
+ * same group operations in another order, and only the group elements are defined.  num_threads only splits each layer's
+ * blocks over threads (test speed); it does not change the result. */
+int oracle_g_to_lagrange(const g1a *g, uint32_t k, g1a *g_lagrange, int num_threads) {
+    oracle_init();
+    if (k > FR_S) return -1;
+    size_t n = (size_t)1 << k;
+    if (num_threads < 1) num_threads = 1;
+    fe n_inv, two, omega_inv = FR_ROOT_OF_UNITY_INV;                     /* :278-282 */
+    fe_from_u64(&two, 2, &FR);
+    fe_inv(&two, &two, &FR);
+    { uint64_t e[4] = {k, 0, 0, 0}; fe_pow(&n_inv, &two, e, 4, &FR); }
+    for (uint32_t i = k; i < FR_S; i++) fe_sqr(&omega_inv, &omega_inv, &FR);
+    g1j *a = (g1j *)malloc(n * sizeof(g1j));
+    for (size_t i = 0; i < n; i++) g1j_from_affine(&a[i], &g[i]);        /* g.to_curve() (commitment.rs:274) */
+    for (size_t i = 0; i < n; i++) {                                     /* best_fft :186-191 */
+        size_t ri = bitreverse(i, k);
+        if (i < ri) { g1j t = a[ri]; a[ri] = a[i]; a[i] = t; }
+    }
+    size_t nt = n / 2;
+    fe *tw = (fe *)malloc((nt ? nt : 1) * sizeof(fe));
+    fe w = FR.r;
+    for (size_t i = 0; i < nt; i++) { tw[i] = w; fe_mul(&w, &w, &omega_inv, &FR); }
+    size_t chunk = 2, twiddle_chunk = n / 2;
+    for (uint32_t s = 0; s < k; s++) {
+        size_t blocks = n / chunk;
+        int T = (size_t)num_threads < blocks ? num_threads : (int)blocks;
+        if (T <= 1) {
+            for (size_t b = 0; b < n; b += chunk) g1_butterfly_layer(a + b, a + b + chunk / 2, chunk / 2, twiddle_chunk, tw);
+        } else {
+            pthread_t th[64];
+            g1_layer_job jobs[64];
+            if (T > 64) T = 64;
+            for (int t = 0; t < T; t++) {
+                size_t b0 = blocks * t / T, b1 = blocks * (t + 1) / T;
+                jobs[t] = (g1_layer_job){a, n, b0 * chunk, b1 * chunk, chunk, twiddle_chunk, tw};
+                pthread_create(&th[t], NULL, g1_layer_thread, &jobs[t]);
+            }
+            for (int t = 0; t < T; t++) pthread_join(th[t], NULL);
+        }
+        chunk *= 2;
+        twiddle_chunk /= 2;
+    }
+    uint64_t e[4];
+    fe_to_canonical(e, &n_inv, &FR);
+    for (size_t i = 0; i < n; i++) {                                     /* :286-290 then batch_normalize :292-298 */
+        g1j t;
+        g1j_mul_canonical(&t, &a[i], e);
+        g1j_to_affine(&g_lagrange[i], &t);
+    }
+    free(tw);
+    free(a);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ synthetic inputs */
 
 static inline uint64_t splitmix64(uint64_t x) {

@@ -223,6 +223,17 @@ def kzg_setup(k, secret_mont):
     return g, gl
 
 
+def g_to_lagrange(g, k, num_threads=1):
+    """arithmetic.rs:277-301: (n, 8) affine coefficient-basis points -> (n, 8) affine Lagrange-basis points"""
+    g = _c(g)
+    assert g.shape[0] == 1 << k
+    out = np.zeros((1 << k, 8), dtype=np.uint64)
+    rc = lib().oracle_g_to_lagrange(_p(g), ctypes.c_uint32(k), _p(out), int(num_threads))
+    if rc != 0:
+        raise ValueError("oracle_g_to_lagrange rc=%d" % rc)
+    return out
+
+
 def gen_scalars(seed, n, start=0, num_threads=1):
     out = np.zeros((n, 4), dtype=np.uint64)
     if start == 0 and num_threads > 1:

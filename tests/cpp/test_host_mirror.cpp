@@ -46,6 +46,20 @@ static void test_commit_lagrange(const std::string& dir) {
     auto b = domain.lagrange_to_coeff(a);
     Blind alpha{Fr::from(12345)};
     CHECK(params.commit(b, alpha) == params.commit_lagrange(a, alpha));
+    // the fixture's g_lagrange is g_to_lagrange(g) (arithmetic.rs:277-301), and downsize (:267-275) keeps the identity
+    CHECK(arithmetic::g_to_lagrange(params.g, K) == params.g_lagrange);
+    {
+        ParamsKZG small;
+        std::ifstream f2(dir + "/kzg_6_params.rawbytes", std::ios::binary);
+        ParamsKZG::read(f2, small);
+        small.downsize(4);
+        CHECK(small.k == 4 && small.g.size() == 16 && small.g_lagrange.size() == 16);
+        EvaluationDomain d4(1, 4);
+        auto a4 = d4.empty_lagrange();
+        for (size_t i = 0; i < a4.len(); i++) a4[i] = Fr::from(3 * i + 1);
+        CHECK(small.commit(d4.lagrange_to_coeff(a4), alpha) == small.commit_lagrange(a4, alpha));
+        CHECK(panics([&] { small.downsize(5); }));
+    }
     // the blind is ignored by KZG commit (poly/kzg/commitment.rs:284,327)
     CHECK(params.commit(b, Blind{Fr::zero()}).to_affine() == params.commit(b, alpha).to_affine());
 }

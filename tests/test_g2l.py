@@ -1,0 +1,76 @@
+"""g_to_lagrange (arithmetic.rs:277-301; best_fft with G = G1, used by ParamsKZG::downsize, poly/kzg/commitment.rs:267-275):
+the oracle against the definition-minted golden vectors and against ParamsKZG::setup's closed-form g_lagrange (CPU), and
+the HIP implementation against the oracle (GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def g2l_golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "g2l.npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("k", range(0, 6))
+def test_oracle_g_to_lagrange_golden(oracle, g2l_golden, k):
+    got = oracle.g_to_lagrange(g2l_golden["g2l_k%d_g" % k], k)
+    assert np.array_equal(got, g2l_golden["g2l_k%d_out" % k])
+
+
+def test_oracle_g_to_lagrange_matches_setup(oracle):
+    """ParamsKZG::setup computes g_lagrange from the secret in closed form (poly/kzg/commitment.rs:89-117); g_to_lagrange of
+    the same setup's g must give the same points -- two independent routes to [l_i(s)]G"""
+    k = 5
+    s = oracle.gen_scalars(4242, 1)[0]
+    g, gl = oracle.kzg_setup(k, s)
+    assert np.array_equal(oracle.g_to_lagrange(g, k, num_threads=4), gl)
+
+
+def test_golden_kzg_params_g_lagrange(oracle, golden):
+    """the RawBytes SRS fixture (k = 6): its g_lagrange is g_to_lagrange(g)"""
+    raw = np.fromfile(os.path.join(ROOT, "tests", "golden", "kzg_6_params.rawbytes"), dtype=np.uint8)
+    k = int(raw[:4].view("<u4")[0])
+    n = 1 << k
+    pts = raw[4:4 + 2 * n * 64].view("<u8").reshape(2, n, 8)
+    assert np.array_equal(oracle.g_to_lagrange(pts[0].copy(), k, num_threads=4), pts[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", range(0, 6))
+def test_gpu_g_to_lagrange_golden(h2, g2l_golden, k):
+    got = h2.g_to_lagrange(g2l_golden["g2l_k%d_g" % k], k)
+    assert np.array_equal(got, g2l_golden["g2l_k%d_out" % k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [7, 10, 12])
+def test_gpu_g_to_lagrange_vs_oracle(h2, oracle, k):
+    g = oracle.gen_points(900 + k, 1 << k, num_threads=8)
+    if k == 7:
+        g[5] = 0  # an identity among the inputs
+    want = oracle.g_to_lagrange(g, k, num_threads=16)
+    assert np.array_equal(h2.g_to_lagrange(g, k), want)
+
+
+@pytest.mark.gpu
+def test_gpu_downsize_commit_lagrange_identity(h2, oracle):
+    """ParamsKZG::downsize (poly/kzg/commitment.rs:267-275) then the reference's own test_commit_lagrange identity
+    (:361-384) at the smaller size: commit(lagrange_to_coeff(a)) == commit_lagrange(a) with g_lagrange from the GPU"""
+    K, k = 12, 9
+    # g = [s^i]G for i < 2^K is too slow to mint at K = 12 on one core with the oracle's scalar ladder; random points
+    # are as good for the identity, which is linear algebra over the group
+    g = oracle.gen_points(31337, 1 << K, num_threads=8)
+    params = h2.ParamsKZG(K, g, g_lagrange=None)
+    params.downsize(k)
+    assert params.k == k and params.g.shape[0] == 1 << k and params.g_lagrange.shape[0] == 1 << k
+    od, _ = oracle.domain_new(2, k)
+    d = h2.EvaluationDomain(od.k, od.extended_k, od.quotient_poly_degree, **{f: od.fe(f) for f in h2.EvaluationDomain.FIELDS})
+    a = oracle.gen_scalars(5, 1 << k)
+    coeffs = d.lagrange_to_coeff(a)
+    lhs = h2.g1_to_affine(params.commit(coeffs))
+    rhs = h2.g1_to_affine(params.commit_lagrange(a))
+    assert np.array_equal(lhs, rhs)
+    params.close()
