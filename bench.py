@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="also time a pipelined batch of this many MSMs (extra key; 0/1 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the evaluate_h / g_to_lagrange legs (SURVEY.md 8(f).3, (f).4)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -177,6 +178,25 @@ def main():
         }
         del d_a
 
+    # ---- SURVEY.md 8(f).3 / (f).4 legs (extra keys; rank 0, N = 1 only), outside the MSM timed region ----
+    next_rows = None
+    if rank == 0 and world == 1 and not args.no_next_rows:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import evalh_bench
+        import g2l_bench
+        eh = evalh_bench.bench(evalh_bench.default_args(k=18, check_k=12, iters=5))
+        gl = g2l_bench.bench(argparse.Namespace(k=[12, 16], cpu_k=12, threads=min(16, os.cpu_count() or 1)))
+        next_rows = {
+            "evaluate_h": {"workload": "2^20 extended rows (k = 18), %d gate polynomials, %d advice + %d fixed columns, %d permutation columns, "
+                                       "%d lookups; device-resident" % (eh["gates"], eh["advice"], eh["fixed"], eh["perm_columns"], eh["lookups"]),
+                           "ms_per_call": eh["k18"]["gpu_ms"], "rows_per_s": eh["k18"]["rows_per_s"],
+                           "parity_vs_cpu_k12": eh["check_k12"]["match"], "cpu_port_s_k12": eh["check_k12"]["oracle_s"],
+                           "gpu_ms_k12": eh["check_k12"]["gpu_ms"]},
+            "g_to_lagrange": {"k16_ms": gl["k16"]["gpu_ms"], "k16_scalar_muls_per_s": gl["k16"]["scalar_muls_per_s"],
+                              "k12_ms": gl["k12"]["gpu_ms"], "cpu_port_s_k12": gl["k12"]["oracle_s"], "cpu_threads": gl["k12"]["oracle_threads"],
+                              "parity_vs_cpu_k12": gl["k12"]["match"]},
+        }
+
     # ---- CPU baseline (rank 0, N = 1 only): the oracle's best_multiexp on the same inputs ----
     cpu = None
     parity = None
@@ -245,6 +265,7 @@ def main():
             "parity_vs_cpu": parity,
             "batched": batched,
             "ntt": ntt,
+            "next_rows": next_rows,
         }
         print(json.dumps(out))
     if world > 1:

@@ -38,18 +38,8 @@ def build_system(ev, args, rng):
     return ev.Evaluator.new(gates, lookups)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--k", type=int, default=18)
-    ap.add_argument("--check-k", type=int, default=12, help="size at which the GPU result is compared with the oracle (0 = skip)")
-    ap.add_argument("--gates", type=int, default=24)
-    ap.add_argument("--advice", type=int, default=12)
-    ap.add_argument("--fixed", type=int, default=10)
-    ap.add_argument("--perm", type=int, default=9)
-    ap.add_argument("--lookups", type=int, default=2)
-    ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--cpu", action="store_true", help="time the oracle at --k too (single thread)")
-    args = ap.parse_args()
+def bench(args):
+    """args: namespace with k, check_k, gates, advice, fixed, perm, lookups, iters, cpu -> result dict"""
     import importlib
     import torch
     h2 = load_pkg()
@@ -148,7 +138,29 @@ def main():
     if args.check_k:
         out["check_k%d" % args.check_k] = run(args.check_k, True, False)
     out["k%d" % args.k] = run(args.k, False, args.cpu)
-    print(json.dumps(out))
+    return out
+
+
+def default_args(**over):
+    ns = argparse.Namespace(k=18, check_k=12, gates=24, advice=12, fixed=10, perm=9, lookups=2, iters=5, cpu=False)
+    for key, v in over.items():
+        setattr(ns, key, v)
+    return ns
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--k", type=int, default=18)
+    ap.add_argument("--check-k", type=int, default=12, help="size at which the GPU result is compared with the oracle (0 = skip)")
+    ap.add_argument("--gates", type=int, default=24)
+    ap.add_argument("--advice", type=int, default=12)
+    ap.add_argument("--fixed", type=int, default=10)
+    ap.add_argument("--perm", type=int, default=9)
+    ap.add_argument("--lookups", type=int, default=2)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--cpu", action="store_true", help="time the oracle at --k too (single thread)")
+    args = ap.parse_args()
+    print(json.dumps(bench(args)))
 
 
 if __name__ == "__main__":

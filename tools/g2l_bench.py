@@ -15,12 +15,8 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_pkg  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--k", type=int, nargs="+", default=[12, 16])
-    ap.add_argument("--cpu-k", type=int, default=12)
-    ap.add_argument("--threads", type=int, default=16)
-    args = ap.parse_args()
+def bench(args):
+    """args: namespace with k (list), cpu_k, threads -> result dict"""
     import torch
     h2 = load_pkg()
     from oracle import oracle as orc
@@ -55,7 +51,15 @@ def main():
             r["match"] = bool(np.array_equal(h2.to_numpy_u64(res), want))
             assert r["match"]
         out["k%d" % k] = r
-    print(json.dumps(out))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--k", type=int, nargs="+", default=[12, 16])
+    ap.add_argument("--cpu-k", type=int, default=12)
+    ap.add_argument("--threads", type=int, default=16)
+    print(json.dumps(bench(ap.parse_args())))
 
 
 if __name__ == "__main__":
