@@ -38,6 +38,17 @@ FIELD_MUL_PER_BUCKET_ADD = 9.2  # XYZZ mixed add: 7 products + 2 squares + one t
 FIELD_MUL_PEAK_G = 179.0  # measured peak of csrc/fieldu.cuh's multiplier on MI355X, G multiplies/s (tools/mul_rate.hip)
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def pmc_traffic(workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass
     (profiles/*_pmc_traffic.json, made by tools/pmc_traffic.py), or None when absent."""
@@ -208,7 +219,7 @@ def main():
         times = []
         cpu_out = None
         budget = time.perf_counter() + 30.0
-        while len(times) < 3 and time.perf_counter() < budget:
+        while len(times) < 5 and time.perf_counter() < budget:
             t1 = time.perf_counter()
             cpu_out = oracle.best_multiexp(sc, bs, cores)
             times.append(time.perf_counter() - t1)
@@ -219,6 +230,7 @@ def main():
             "unit": "G1-adds/s",
             "pairs_per_s": n / tmed,
             "cores": cores,
+            "cpu_model": cpu_model(),
             "kind": "port",
             "sample": "full 2^%d-pair MSM, median of %d runs, %.3f s each; C restatement of best_multiexp "
                       "(chunk = n/T per thread, c = %d unsigned windows), not the Rust binary" % (args.log_n, len(times), tmed, cpu_c),
