@@ -185,7 +185,10 @@ def main():
             "ms_per_transform": ms,
             "elems_per_s": (1 << k) / (ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": NTT_BYTES_PER_ELEM * (1 << k) / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": NTT_BYTES_PER_ELEM * (1 << k) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                         "unit": "GB/s", "frac": NTT_BYTES_PER_ELEM * (1 << k) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         # PMC bytes of one transform = two strided passes + the final pass (committed --pmc runs, 2^22 only)
+                         "traffic": (2 * st + fi) if (k == 22 and (st := pmc_traffic("ntt_2p22_strided")) and (fi := pmc_traffic("ntt_2p22_final")))
+                         else None},
         }
         del d_a
 
