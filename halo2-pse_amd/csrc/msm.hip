@@ -375,7 +375,7 @@ struct MsmLayout {
     int end_bit;
     size_t cub_bytes, max_chunks, max_heavy;
     size_t o_keys0, o_keys1, o_vals0, o_vals1, o_cub, o_start, o_end, o_counts, o_perm, o_hist, o_buckets, o_acc, o_run, o_wsum, o_T, o_hcnt,
-        o_hb, o_hc, o_hs, total;
+        o_hb, o_hc, o_hs, o_zero_end, total;
 };
 
 static int msm_layout(size_t n, hipStream_t s, MsmLayout* L) {
@@ -426,16 +426,17 @@ static int msm_layout(size_t n, hipStream_t s, MsmLayout* L) {
     L->o_keys0 = carve(E * 4); L->o_keys1 = carve(E * 4); L->o_vals0 = carve(E * 4); L->o_vals1 = carve(E * 4);
     L->o_cub = carve(L->cub_bytes);
     L->o_start = carve(((size_t)nb + 2) * 4);
-    L->o_end = carve(((size_t)nb + 2) * 4);  // directly after start: one memset clears both
+    L->o_end = carve(((size_t)nb + 2) * 4);
+    L->o_hist = carve(512 * 4);
+    L->o_hcnt = carve(16);
+    L->o_zero_end = off;  // start[], end[], hist[], heavy counters are contiguous: one memset clears them all
     L->o_counts = carve((size_t)nb * 4);
     L->o_perm = carve((size_t)nb * 4);
-    L->o_hist = carve(512 * 4);
     L->o_buckets = carve((size_t)nb * sizeof(XYZZu));
     L->o_acc = carve((size_t)p.W * L->m1 * sizeof(XYZZu));
     L->o_run = carve((size_t)p.W * L->m1 * sizeof(XYZZu));
     L->o_wsum = carve((size_t)p.W * sizeof(XYZZ));
     L->o_T = carve((size_t)p.W * (L->D + 1) * 32 * sizeof(XYZZu));
-    L->o_hcnt = carve(16);
     L->o_hb = carve(L->max_heavy * sizeof(HeavyBucket));
     L->o_hc = carve(L->max_chunks * sizeof(HeavyChunk));
     L->o_hs = carve(L->max_chunks * sizeof(XYZZu));
@@ -452,9 +453,7 @@ static int msm_stage_a(Ctx* c, const MsmLayout& L, char* base, const Fe* d_scala
     uint32_t *start = (uint32_t*)(base + L.o_start), *endp = (uint32_t*)(base + L.o_end);
     uint32_t *counts = (uint32_t*)(base + L.o_counts), *perm = (uint32_t*)(base + L.o_perm), *hist = (uint32_t*)(base + L.o_hist);
     int t0 = c->timer_begin("msm_digits", s);
-    H2_CHECK(hipMemsetAsync(base + L.o_hcnt, 0, 16, s));
-    H2_CHECK(hipMemsetAsync(start, 0, L.o_counts - L.o_start, s));  // start[] and end[]
-    H2_CHECK(hipMemsetAsync(hist, 0, 512 * 4, s));
+    H2_CHECK(hipMemsetAsync(start, 0, L.o_zero_end - L.o_start, s));  // start[], end[], hist[], heavy counters
     hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, d_scalars, (uint32_t)n, p.c, p.W, p.NB, keys0, vals0);
     H2_CHECK(hipGetLastError());
     c->timer_end(t0, s);

@@ -333,3 +333,62 @@ def test_cpp_graph_evaluator_matches_golden_graphs(evalh_golden, tmp_path):
         assert np.array_equal(np.array(got[(name, "rotation")], dtype=np.int32).reshape(-1), evalh_golden[p + "rotations"])
         assert np.array_equal(np.array(got[(name, "calc")], dtype=np.uint32), evalh_golden[p + "calcs"])
         assert np.array_equal(np.array(got.get((name, "part"), []), dtype=np.uint32).reshape(-1, 3), evalh_golden[p + "parts"])
+
+
+def _strip(case, perm=True, lookups=True):
+    c = dict(case)
+    if not perm:
+        c["perm_product_cosets"], c["perm_cosets"] = [], []
+        c["perm_column_kind"] = np.zeros(0, dtype=np.uint32)
+        c["perm_column_index"] = np.zeros(0, dtype=np.uint32)
+    if not lookups:
+        c["lookups"] = []
+    return c
+
+
+@pytest.mark.parametrize("variant", ["no_perm", "no_lookups", "gates_only", "empty_graph", "horner_without_parts"])
+def test_oracle_evaluate_h_degenerate_systems(oracle, variant):
+    """the reference's loops simply do not run for a system without permutation / lookups (evaluation.rs:362, :443); an
+    Evaluator with no gates still holds Horner(PreviousValue, [], y) and returns the previous value; a GraphEvaluator with
+    no calculations evaluates to zero (:745-749).  Pinned here on the oracle by hand-computable outcomes."""
+    from evalh_util import GraphEvaluator, custom_gates_graph, flatten_graph
+    case, vin = _random_case(oracle, 4, seed=9)
+    if variant == "horner_without_parts":
+        case = _strip(case, perm=False, lookups=False)
+        case["custom"] = flatten_graph(custom_gates_graph([]))
+        want = vin  # unchanged
+    elif variant == "empty_graph":
+        case = _strip(case, perm=False, lookups=False)
+        case["custom"] = flatten_graph(GraphEvaluator())
+        want = np.zeros_like(vin)
+    else:
+        case = _strip(case, perm=variant not in ("no_perm", "gates_only"), lookups=variant not in ("no_lookups", "gates_only"))
+        want = None
+    h = DescHolder(case)
+    got = vin.copy()
+    assert oracle.lib().oracle_evaluate_h(h.byref(), got.ctypes.data_as(ctypes.c_void_p)) == 0
+    if want is not None:
+        assert np.array_equal(got, want)
+    else:
+        assert not np.array_equal(got, vin)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["no_perm", "no_lookups", "gates_only", "empty_graph", "horner_without_parts"])
+def test_gpu_evaluate_h_degenerate_systems(h2, oracle, variant):
+    from evalh_util import GraphEvaluator, custom_gates_graph, flatten_graph
+    case, vin = _random_case(oracle, 6, seed=10)
+    if variant == "horner_without_parts":
+        case = _strip(case, perm=False, lookups=False)
+        case["custom"] = flatten_graph(custom_gates_graph([]))
+    elif variant == "empty_graph":
+        case = _strip(case, perm=False, lookups=False)
+        case["custom"] = flatten_graph(GraphEvaluator())
+    else:
+        case = _strip(case, perm=variant not in ("no_perm", "gates_only"), lookups=variant not in ("no_lookups", "gates_only"))
+    h = DescHolder(case)
+    want = vin.copy()
+    assert oracle.lib().oracle_evaluate_h(h.byref(), want.ctypes.data_as(ctypes.c_void_p)) == 0
+    got = vin.copy()
+    assert h2.lib().h2hip_evaluate_h_bn254(h.byref(), got.ctypes.data_as(ctypes.c_void_p)) == 0, h2.lib().h2hip_last_error()
+    assert np.array_equal(got, want)

@@ -74,3 +74,17 @@ def test_gpu_downsize_commit_lagrange_identity(h2, oracle):
     rhs = h2.g1_to_affine(params.commit_lagrange(a))
     assert np.array_equal(lhs, rhs)
     params.close()
+
+
+def test_g_to_lagrange_rejects_bad_arguments(h2):
+    """contract violations are H2HIP_EINVAL before any device work"""
+    import ctypes
+    L = h2.lib()
+    buf = np.zeros((2, 8), dtype=np.uint64)
+    p = buf.ctypes.data_as(ctypes.c_void_p)
+    assert L.h2hip_g_to_lagrange_bn254(None, ctypes.c_uint32(1), p) == 1
+    assert L.h2hip_g_to_lagrange_bn254(p, ctypes.c_uint32(1), None) == 1
+    assert L.h2hip_g_to_lagrange_bn254(p, ctypes.c_uint32(29), p) == 1   # beyond the 2-adicity of Fr
+    assert b"g_to_lagrange" in L.h2hip_last_error()
+    with pytest.raises(AssertionError):
+        h2.g_to_lagrange(np.zeros((3, 8), dtype=np.uint64), 2)           # a.len() == 1 << log_n (arithmetic.rs:184)
