@@ -325,6 +325,27 @@ def extended_to_coeff_device(d_a, extended_k, extended_omega_inv, extended_ifft_
            "h2hip_extended_to_coeff_bn254_fr_device")
 
 
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * max(1, len(tensors)))(*[t.data_ptr() for t in tensors])
+
+
+def ntt_batch_device(d_list, omega, log_n):
+    """the same NTT over every tensor of d_list, one launch per pass"""
+    _check(lib().h2hip_ntt_bn254_fr_batch_device(_ptr_array(d_list), ctypes.c_size_t(len(d_list)), _p(_fe(omega)), ctypes.c_uint32(log_n), _stream()),
+           "h2hip_ntt_bn254_fr_batch_device")
+
+
+def ifft_batch_device(d_list, omega_inv, log_n, divisor):
+    _check(lib().h2hip_ifft_bn254_fr_batch_device(_ptr_array(d_list), ctypes.c_size_t(len(d_list)), _p(_fe(omega_inv)), ctypes.c_uint32(log_n),
+                                                  _p(_fe(divisor)), _stream()), "h2hip_ifft_bn254_fr_batch_device")
+
+
+def coeff_to_extended_batch_device(d_list, k, extended_k, extended_omega, g_coset, g_coset_inv):
+    _check(lib().h2hip_coeff_to_extended_bn254_fr_batch_device(_ptr_array(d_list), ctypes.c_size_t(len(d_list)), ctypes.c_uint32(k),
+                                                               ctypes.c_uint32(extended_k), _p(_fe(extended_omega)), _p(_fe(g_coset)),
+                                                               _p(_fe(g_coset_inv)), _stream()), "h2hip_coeff_to_extended_bn254_fr_batch_device")
+
+
 def gen_scalars_device(seed, n, start=0, device="cuda"):
     import torch
     out = torch.empty((n, 4), dtype=torch.int64, device=device)

@@ -324,6 +324,7 @@ void h2hip_shutdown(void) {
     c->evalh_ws.release();
     c->evalh_slots.release();
     c->ecfft_ws.release();
+    c->ntt_ptrs.release();
     (void)hipStreamDestroy(c->stream);
     c->stream = nullptr;
     for (auto e : c->aux_events) (void)hipEventDestroy(e);
@@ -737,6 +738,53 @@ int h2hip_divide_by_vanishing_poly_bn254_fr(uint64_t* a, uint32_t extended_k, co
     H2_CHECK(hipMemcpyAsync(a, c->ntt_io.p, bytes, hipMemcpyDeviceToHost, c->stream));
     H2_CHECK(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+// ---- batched device-resident transforms: `count` columns of the same size, one launch per NTT pass
+static int batch_args_ok(void* const* d_a, size_t count, uint32_t log_n, const char* what) {
+    if (log_n > 28 || (count && !d_a)) {
+        set_error("%s: bad argument", what);
+        return 0;
+    }
+    for (size_t i = 0; i < count; i++)
+        if (!d_a[i]) {
+            set_error("%s: null column %zu", what, i);
+            return 0;
+        }
+    return 1;
+}
+
+int h2hip_ntt_bn254_fr_batch_device(void* const* d_a, size_t count, const uint64_t omega[4], uint32_t log_n, void* stream) {
+    if (!omega || !batch_args_ok(d_a, count, log_n, "ntt_batch")) return H2HIP_EINVAL;
+    if (check_fr(omega, "omega")) return H2HIP_EINVAL;
+    Entry en;
+    if (en.rc) return en.rc;
+    return ntt_device_batch(en.c, (Fe* const*)d_a, nullptr, count, fe_from_u64x4(omega), log_n, nullptr, (hipStream_t)stream);
+}
+
+int h2hip_ifft_bn254_fr_batch_device(void* const* d_a, size_t count, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4],
+                                     void* stream) {
+    if (!omega_inv || !divisor || !batch_args_ok(d_a, count, log_n, "ifft_batch")) return H2HIP_EINVAL;
+    if (check_fr(omega_inv, "omega_inv") || check_fr(divisor, "divisor")) return H2HIP_EINVAL;
+    Entry en;
+    if (en.rc) return en.rc;
+    NttScale sc;
+    sc.out_scale = true;
+    sc.out3[0] = sc.out3[1] = sc.out3[2] = fe_from_u64x4(divisor);
+    return ntt_device_batch(en.c, (Fe* const*)d_a, nullptr, count, fe_from_u64x4(omega_inv), log_n, &sc, (hipStream_t)stream);
+}
+
+int h2hip_coeff_to_extended_bn254_fr_batch_device(void* const* d_a, size_t count, uint32_t k, uint32_t extended_k, const uint64_t extended_omega[4],
+                                                  const uint64_t g_coset[4], const uint64_t g_coset_inv[4], void* stream) {
+    if (!extended_omega || !g_coset || !g_coset_inv || k > extended_k || !batch_args_ok(d_a, count, extended_k, "coeff_to_extended_batch"))
+        return H2HIP_EINVAL;
+    if (check_fr(extended_omega, "extended_omega") || check_fr(g_coset, "g_coset") || check_fr(g_coset_inv, "g_coset_inv")) return H2HIP_EINVAL;
+    Entry en;
+    if (en.rc) return en.rc;
+    NttScale sc;
+    make_zeta_scale(&sc, true, g_coset, g_coset_inv, nullptr);
+    sc.in_len = 1ull << k;
+    return ntt_device_batch(en.c, (Fe* const*)d_a, nullptr, count, fe_from_u64x4(extended_omega), extended_k, &sc, (hipStream_t)stream);
 }
 
 int h2hip_g_to_lagrange_bn254_device(const void* d_g_xy, uint32_t k, void* d_g_lagrange_xy, void* stream) {

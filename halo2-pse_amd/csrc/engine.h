@@ -76,7 +76,7 @@ struct Ctx {
     bool ready = false;
     hipStream_t stream = nullptr;  // the engine's own stream (host-pointer entry points)
     std::recursive_mutex mu;       // serialises entry points: re-entrant callers (rayon workers) are safe
-    DevBuf ntt_ws, ntt_io, msm_scalars[3], msm_bases, msm_slot[3], misc, evalh_ws, evalh_slots, ecfft_ws;
+    DevBuf ntt_ws, ntt_io, msm_scalars[3], msm_bases, msm_slot[3], misc, evalh_ws, evalh_slots, ecfft_ws, ntt_ptrs;
     HostBuf host_ws;               // pinned host memory for the window sums coming back
     std::map<TwiddleKey, TwiddleTable> twiddles;
     std::map<const void*, PinnedBases> pinned;
@@ -117,6 +117,9 @@ struct NttScale {
 // d_src (optional): the first pass reads its input there instead of d_data (which is then output only); with
 // sc->in_len set only d_src[0 .. in_len) is read
 int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttScale* sc, hipStream_t s, const Fe* d_src = nullptr);
+
+int ntt_device_batch(Ctx* c, Fe* const* h_datas, const Fe* const* h_srcs, size_t count, const Fe& omega, uint32_t log_n, const NttScale* sc,
+                     hipStream_t s);
 
 int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const uint64_t* h_t, uint32_t t_len, hipStream_t s);
 

@@ -554,24 +554,29 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         sc.in3[2] = load_fe(d->g_coset_inv);
         sc.in_len = n;
     }
-    auto poly_to_coset = [&](const uint64_t* h, Fe** out) -> int {
-        if (!dev) {
-            int r = col_upload(h, n, out);
-            return r ? r : ntt_device(c, *out, ext_omega, ek, &sc, s);
-        }
-        Fe* p = (Fe*)ar.take(col_bytes);  // device-resident coefficients: the first NTT pass reads them where they lie
-        if (!p || !h) {
-            set_error("evaluate_h: null column or arena overflow");
-            return 1;
-        }
-        *out = p;
-        return ntt_device(c, p, ext_omega, ek, &sc, s, (const Fe*)h);
-    };
+    // advice and instance polynomials -> extended cosets (:306-323), all in one batched transform: uploads (or, device
+    // resident, nothing: the first pass reads the coefficients where they lie) first, then one launch per NTT pass
     std::vector<const Fe*> fixed(d->n_fixed), advice(d->n_advice), instance(d->n_instance);
     Fe* tmp;
     for (uint32_t i = 0; i < d->n_fixed; i++) { if ((rc = col_upload(d->fixed_cosets[i], size, &tmp))) return rc; fixed[i] = tmp; }
-    for (uint32_t i = 0; i < d->n_advice; i++) { if ((rc = poly_to_coset(d->advice_polys[i], &tmp))) return rc; advice[i] = tmp; }
-    for (uint32_t i = 0; i < d->n_instance; i++) { if ((rc = poly_to_coset(d->instance_polys[i], &tmp))) return rc; instance[i] = tmp; }
+    {
+        const size_t n_polys = (size_t)d->n_advice + d->n_instance;
+        std::vector<Fe*> datas(n_polys);
+        std::vector<const Fe*> srcs(n_polys, nullptr);
+        for (size_t i = 0; i < n_polys; i++) {
+            const uint64_t* h = i < d->n_advice ? d->advice_polys[i] : d->instance_polys[i - d->n_advice];
+            Fe* p = (Fe*)ar.take(col_bytes);
+            if (!p || !h) {
+                set_error("evaluate_h: null column or arena overflow");
+                return 1;
+            }
+            if (dev) srcs[i] = (const Fe*)h;
+            else H2_CHECK(hipMemcpyAsync(p, h, n * sizeof(Fe), hipMemcpyHostToDevice, s));
+            datas[i] = p;
+            (i < d->n_advice ? advice[i] : instance[i - d->n_advice]) = p;
+        }
+        if ((rc = ntt_device_batch(c, datas.data(), srcs.data(), n_polys, ext_omega, ek, &sc, s))) return rc;
+    }
     Fe *l0, *l_last, *l_active, *d_values;
     if ((rc = col_upload(d->l0, size, &l0)) || (rc = col_upload(d->l_last, size, &l_last)) || (rc = col_upload(d->l_active_row, size, &l_active)) ||
         (rc = col_upload(values, size, &d_values)))
@@ -666,14 +671,16 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
             }
         for (uint32_t i = 0; i < d->n_lookups; i++) {
             const uint64_t* polys[3] = {d->lookup_product_polys[i], d->lookup_permuted_input_polys[i], d->lookup_permuted_table_polys[i]};
+            const Fe* lsrc[3] = {nullptr, nullptr, nullptr};
             for (int t = 0; t < 3; t++) {
                 if (!polys[t]) {
                     set_error("evaluate_h: null lookup polynomial");
                     return 1;
                 }
-                if (!dev) H2_CHECK(hipMemcpyAsync(buf[t], polys[t], n * sizeof(Fe), hipMemcpyHostToDevice, s));
-                if ((rc = ntt_device(c, buf[t], ext_omega, ek, &sc, s, dev ? (const Fe*)polys[t] : nullptr))) return rc;
+                if (dev) lsrc[t] = (const Fe*)polys[t];
+                else H2_CHECK(hipMemcpyAsync(buf[t], polys[t], n * sizeof(Fe), hipMemcpyHostToDevice, s));
             }
+            if ((rc = ntt_device_batch(c, buf, lsrc, 3, ext_omega, ek, &sc, s))) return rc;
             ProgDev lg;
             if ((rc = prog_upload(ar, d->lookup_graphs[i], lookup_progs[i], &lg, s))) return rc;
             LookupDev ld = {buf[0], buf[1], buf[2], l0, l_last, l_active};

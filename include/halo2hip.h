@@ -139,6 +139,17 @@ int h2hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream)
 int h2hip_memset_zero(void* d_dst, size_t bytes, void* stream);
 int h2hip_stream_synchronize(void* stream);
 
+/* ---- batched device-resident transforms: `count` columns of one size in one launch per NTT pass.  d_a is a HOST array of
+ * `count` device pointers; semantics per column are those of the unbatched _device entry points.  create_proof converts
+ * its columns back to back (plonk/prover.rs:487 lagrange_to_coeff per advice column; plonk/evaluation.rs:306-323
+ * coeff_to_extended per advice / instance column): at 2^17..2^20 points per column one transform does not fill the GPU. */
+int h2hip_ntt_bn254_fr_batch_device(void* const* d_a, size_t count, const uint64_t omega[4], uint32_t log_n, void* stream);
+int h2hip_ifft_bn254_fr_batch_device(void* const* d_a, size_t count, const uint64_t omega_inv[4], uint32_t log_n,
+                                     const uint64_t divisor[4], void* stream);
+int h2hip_coeff_to_extended_bn254_fr_batch_device(void* const* d_a, size_t count, uint32_t k, uint32_t extended_k,
+                                                  const uint64_t extended_omega[4], const uint64_t g_coset[4],
+                                                  const uint64_t g_coset_inv[4], void* stream);
+
 /* ---- g_to_lagrange: arithmetic.rs:277-301 (best_fft with G = G1, then 1/n and batch_normalize); called by
  * ParamsKZG::downsize, poly/kzg/commitment.rs:267-275.  g_xy: 2^k affine points (the coefficient-basis SRS, possibly
  * truncated); g_lagrange_xy: 2^k affine points out.  k <= 28.  Input and output may not overlap. */

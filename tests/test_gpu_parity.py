@@ -480,3 +480,54 @@ def test_device_resident_column_flow(h2, oracle):
     finally:
         L.h2hip_device_free(d_col)
         L.h2hip_device_free(d_bases)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [0, 3, 9, 14, 17])
+def test_batched_transforms_equal_single_ones(h2, oracle, k):
+    """h2hip_{ntt,ifft,coeff_to_extended}_bn254_fr_batch_device: every column of the batch equals the unbatched entry point
+    (which is checked against the oracle above) -- 1-, 2- and 3-pass sizes, five columns"""
+    import torch
+    d, _ = oracle.domain_new(4, k)
+    ek = d.extended_k
+    cols = [h2.gen_scalars_device(4000 + i, 1 << ek) for i in range(5)]
+    torch.cuda.synchronize()
+    # NTT over the first 2^k elements of each column
+    want = []
+    for c in cols:
+        t = c[:1 << k].clone()
+        h2.ntt_device(t, d.fe("omega"), k)
+        want.append(t)
+    got = [c[:1 << k].clone() for c in cols]
+    h2.ntt_batch_device(got, d.fe("omega"), k)
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+    # iNTT
+    want = [w.clone() for w in got]
+    for w in want:
+        h2.ifft_device(w, d.fe("omega_inv"), k, d.fe("ifft_divisor"))
+    h2.ifft_batch_device(got, d.fe("omega_inv"), k, d.fe("ifft_divisor"))
+    torch.cuda.synchronize()
+    for g, w, c in zip(got, want, cols):
+        assert torch.equal(g, w) and torch.equal(g, c[:1 << k])
+    # coeff_to_extended in place on the extended-size buffers
+    want = [c.clone() for c in cols]
+    for w in want:
+        h2.coeff_to_extended_device(w, k, ek, d.fe("extended_omega"), d.fe("g_coset"), d.fe("g_coset_inv"))
+    got = [c.clone() for c in cols]
+    h2.coeff_to_extended_batch_device(got, k, ek, d.fe("extended_omega"), d.fe("g_coset"), d.fe("g_coset_inv"))
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+
+
+def test_batched_transforms_reject_bad_arguments(h2):
+    import ctypes
+    L = h2.lib()
+    one = (ctypes.c_uint64 * 4)(1, 0, 0, 0)
+    nul = (ctypes.c_void_p * 2)(None, None)
+    assert L.h2hip_ntt_bn254_fr_batch_device(nul, ctypes.c_size_t(2), one, ctypes.c_uint32(4), None) == 1
+    assert L.h2hip_ntt_bn254_fr_batch_device(None, ctypes.c_size_t(2), one, ctypes.c_uint32(4), None) == 1
+    assert L.h2hip_ntt_bn254_fr_batch_device(nul, ctypes.c_size_t(2), one, ctypes.c_uint32(29), None) == 1
+    assert L.h2hip_coeff_to_extended_bn254_fr_batch_device(nul, ctypes.c_size_t(1), ctypes.c_uint32(5), ctypes.c_uint32(4), one, one, one, None) == 1
