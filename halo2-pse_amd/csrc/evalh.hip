@@ -24,10 +24,26 @@ namespace h2 {
 // The flattened graph is compiled on the host (compile_graph below) into a short register-machine program before it is
 // run: Store calculations become direct column operands, a Horner calculation becomes one FMA per part placed as soon
 // as that part exists, dead calculations are dropped and the surviving intermediates are packed into as few slots as
-// their lifetimes allow.  A slot is 32 B of per-lane scratch (or, past 256 slots, a row of a global workspace), so a
-// circuit with tens of thousands of calculations still runs with a few dozen slots per lane.  The arithmetic performed
-// per row is the reference's, operation for operation; only where a value waits between operations differs.
-enum { OP_ADD = 0, OP_SUB, OP_MUL, OP_SQR, OP_DBL, OP_NEG, OP_MOV, OP_FMA /* dst = dst * y + x */ };
+// their lifetimes allow.  A slot is 36 B of per-lane scratch (or, past 256 slots, a row of a global workspace), so a
+// circuit with tens of thousands of calculations still runs with a few dozen slots per lane.  The field operations
+// performed per row are the reference's, operation for operation; only where a value waits between them differs.
+//
+// Arithmetic: the unsaturated 9 x 29-bit multiplier of fieldu.cuh (the MSM's and the NTT's), about half the
+// instructions of the saturated CIOS.  Inside a kernel every value is I-form (a * 2^261, lazily reduced): a column
+// element (E-form, canonical) becomes I-form for free as the limbs of 32 * x (fu_from_ext), I * I -> I, constants and
+// challenges are converted on the host, and the one value a row writes back goes through the exact reduction
+// fu_mul_canon(x, 2^256) -> canonical E-form.  So what is stored is the reference's field element, limb for limb.
+// Magnitudes (in units of the modulus r) are tracked statically: a loaded column is < 32, a product of magnitudes a, b is
+// < a*b/169 + 1, sums add.  For the interpreter the host walks the straight-line program with these rules and marks the
+// operations after which a reduction (one multiplication by 2^261) must be inserted to stay below EVALH_MAG_LIMIT; the
+// hand-written constraint code below carries its bounds in comments.  Every addition is followed by a carry propagation so
+// that limbs 0..7 are back in [0, 2^29) (fu_mul's operand contract).
+enum { OP_ADD = 0, OP_SUB, OP_MUL, OP_SQR, OP_DBL, OP_NEG, OP_MOV, OP_FMA /* dst = dst * y + x */, OP_REDUCE_FLAG = 0x100 };
+#define EVALH_MAG_LIMIT 100.0   // |value| < 100 r keeps the top limb below 2^28.3
+#define EVALH_MAG_RESULT 15.0   // fu_mul_canon needs |value| < 16 r
+#define EVALH_MAG_COLUMN 32.0   // fu_from_ext of a canonical element
+
+typedef FrUA UF;
 
 struct DevOp {
     uint32_t op, dst;
@@ -35,7 +51,7 @@ struct DevOp {
 };
 
 struct ProgDev {
-    const Fe* constants;
+    const Fu* constants;  // I-form, canonical
     const int32_t* rotations;
     const DevOp* ops;
     uint32_t n_ops;
@@ -46,27 +62,33 @@ struct ColsDev {
     const Fe* const* fixed;
     const Fe* const* advice;
     const Fe* const* instance;
-    const Fe* challenges;
-    Fe beta, gamma, theta, y;
+    const Fu* challenges;  // I-form, canonical
+    Fu beta, gamma, theta, y;
     uint32_t log_size;
     int32_t rot_scale;
 };
 
+__device__ __forceinline__ Fu ld_i(const Fe& x) { return fu_from_ext(x); }                    // E canonical -> I, < 32 r
+__device__ __forceinline__ Fu addn(const Fu& a, const Fu& b) { return fu_norm(fu_add(a, b)); }
+__device__ __forceinline__ Fu subn(const Fu& a, const Fu& b) { return fu_norm(fu_sub(a, b)); }
+__device__ __forceinline__ Fu mul_i(const Fu& a, const Fu& b) { return fu_mul<UF>(a, b); }
+__device__ __forceinline__ Fe out_e(const Fu& a) { return fu_mul_canon<UF>(a, fu_one_e<UF>()); }  // |a| < 16 r -> canonical E
+
 // slot storage: MAXI > 0 -> per-lane scratch; MAXI == 0 -> a global workspace laid out [slot][lane] (coalesced per slot)
 template <int MAXI>
 struct Slots {
-    Fe v[MAXI];
-    __device__ __forceinline__ Slots(Fe*, size_t) {}
-    __device__ __forceinline__ Fe get(uint32_t i) const { return v[i]; }
-    __device__ __forceinline__ void set(uint32_t i, const Fe& x) { v[i] = x; }
+    Fu v[MAXI];
+    __device__ __forceinline__ Slots(Fu*, size_t) {}
+    __device__ __forceinline__ Fu get(uint32_t i) const { return v[i]; }
+    __device__ __forceinline__ void set(uint32_t i, const Fu& x) { v[i] = x; }
 };
 template <>
 struct Slots<0> {
-    Fe* base;
+    Fu* base;
     size_t stride;
-    __device__ __forceinline__ Slots(Fe* b, size_t s) : base(b), stride(s) {}
-    __device__ __forceinline__ Fe get(uint32_t i) const { return base[i * stride]; }
-    __device__ __forceinline__ void set(uint32_t i, const Fe& x) { base[i * stride] = x; }
+    __device__ __forceinline__ Slots(Fu* b, size_t s) : base(b), stride(s) {}
+    __device__ __forceinline__ Fu get(uint32_t i) const { return base[i * stride]; }
+    __device__ __forceinline__ void set(uint32_t i, const Fu& x) { base[i * stride] = x; }
 };
 
 // get_rotation_idx (evaluation.rs:32-34): size is a power of two, so rem_euclid is a mask
@@ -76,53 +98,74 @@ __device__ __forceinline__ uint32_t rot_idx(uint32_t idx, int32_t rot, int32_t r
 
 // ValueSource::get (evaluation.rs:68-103)
 template <class S>
-__device__ __forceinline__ Fe vs_get(const ProgDev& g, const ColsDev& c, const h2hip_value_source& v, uint32_t idx, const S& slots,
-                                     const Fe& previous) {
+__device__ __forceinline__ Fu vs_get(const ProgDev& g, const ColsDev& c, const h2hip_value_source& v, uint32_t idx, const S& slots,
+                                     const Fu& previous) {
     switch (v.kind) {
         case H2HIP_VS_CONSTANT: return g.constants[v.a];
         case H2HIP_VS_INTERMEDIATE: return slots.get(v.a);
-        case H2HIP_VS_FIXED: return c.fixed[v.a][rot_idx(idx, g.rotations[v.b], c.rot_scale, c.log_size)];
-        case H2HIP_VS_ADVICE: return c.advice[v.a][rot_idx(idx, g.rotations[v.b], c.rot_scale, c.log_size)];
-        case H2HIP_VS_INSTANCE: return c.instance[v.a][rot_idx(idx, g.rotations[v.b], c.rot_scale, c.log_size)];
+        case H2HIP_VS_FIXED: return ld_i(c.fixed[v.a][rot_idx(idx, g.rotations[v.b], c.rot_scale, c.log_size)]);
+        case H2HIP_VS_ADVICE: return ld_i(c.advice[v.a][rot_idx(idx, g.rotations[v.b], c.rot_scale, c.log_size)]);
+        case H2HIP_VS_INSTANCE: return ld_i(c.instance[v.a][rot_idx(idx, g.rotations[v.b], c.rot_scale, c.log_size)]);
         case H2HIP_VS_CHALLENGE: return c.challenges[v.a];
         case H2HIP_VS_BETA: return c.beta;
         case H2HIP_VS_GAMMA: return c.gamma;
         case H2HIP_VS_THETA: return c.theta;
         case H2HIP_VS_Y: return c.y;
         case H2HIP_VS_PREVIOUS: return previous;
-        default: return fe_zero<FrP>();
+        default: return fu_zero();
     }
 }
 
-// GraphEvaluator::evaluate (evaluation.rs:708-749) with Calculation::evaluate (:129-178), over the compiled program
+// GraphEvaluator::evaluate (evaluation.rs:708-749) with Calculation::evaluate (:129-178), over the compiled program.
+// Returns the I-form result; the host guarantees its magnitude is below EVALH_MAG_RESULT when it is a slot (a column or a
+// constant can also be the result of a degenerate graph: < 32).
 template <class S>
-__device__ Fe prog_eval(const ProgDev& g, const ColsDev& c, uint32_t idx, const Fe& previous, S& slots) {
+__device__ Fu prog_eval(const ProgDev& g, const ColsDev& c, uint32_t idx, const Fu& previous, S& slots) {
     for (uint32_t q = 0; q < g.n_ops; q++) {
         const DevOp o = g.ops[q];
-        const Fe a = vs_get(g, c, o.x, idx, slots, previous);
-        Fe out;
-        switch (o.op) {
-            case OP_ADD: out = fe_add<FrP>(a, vs_get(g, c, o.y, idx, slots, previous)); break;
-            case OP_SUB: out = fe_sub<FrP>(a, vs_get(g, c, o.y, idx, slots, previous)); break;
-            case OP_MUL: out = fe_mul<FrP>(a, vs_get(g, c, o.y, idx, slots, previous)); break;
-            case OP_SQR: out = fe_sqr<FrP>(a); break;
-            case OP_DBL: out = fe_dbl<FrP>(a); break;
-            case OP_NEG: out = fe_neg<FrP>(a); break;
-            case OP_FMA: out = fe_add<FrP>(fe_mul<FrP>(slots.get(o.dst), vs_get(g, c, o.y, idx, slots, previous)), a); break;
+        const Fu a = vs_get(g, c, o.x, idx, slots, previous);
+        Fu out;
+        switch (o.op & 0xff) {
+            case OP_ADD: out = addn(a, vs_get(g, c, o.y, idx, slots, previous)); break;
+            case OP_SUB: out = subn(a, vs_get(g, c, o.y, idx, slots, previous)); break;
+            case OP_MUL: out = mul_i(a, vs_get(g, c, o.y, idx, slots, previous)); break;
+            case OP_SQR: out = fu_sqr<UF>(a); break;
+            case OP_DBL: out = fu_norm(fu_dbl(a)); break;
+            case OP_NEG: out = fu_norm(fu_neg(a)); break;
+            case OP_FMA: out = addn(mul_i(slots.get(o.dst), vs_get(g, c, o.y, idx, slots, previous)), a); break;
             default: out = a;  // OP_MOV
         }
+        if (o.op & OP_REDUCE_FLAG) out = mul_i(out, fu_one_i<UF>());
         slots.set(o.dst, out);
     }
     return vs_get(g, c, g.result, idx, slots, previous);
 }
 
+// the value a row stores: a column / PreviousValue result is already the canonical element
+template <class S>
+__device__ __forceinline__ Fe prog_result_e(const ProgDev& g, const ColsDev& c, uint32_t idx, const Fe& previous_e, const Fu& r) {
+    switch (g.result.kind) {
+        case H2HIP_VS_FIXED: return c.fixed[g.result.a][rot_idx(idx, g.rotations[g.result.b], c.rot_scale, c.log_size)];
+        case H2HIP_VS_ADVICE: return c.advice[g.result.a][rot_idx(idx, g.rotations[g.result.b], c.rot_scale, c.log_size)];
+        case H2HIP_VS_INSTANCE: return c.instance[g.result.a][rot_idx(idx, g.rotations[g.result.b], c.rot_scale, c.log_size)];
+        case H2HIP_VS_PREVIOUS: return previous_e;
+        case EVALH_VS_ZERO: return fe_zero<FrP>();
+        default: return out_e(r);
+    }
+}
+
 // lanes = threads in the grid; rows beyond it are taken grid-stride (only the global-workspace form launches fewer lanes than rows)
 template <int MAXI>
-__global__ void __launch_bounds__(256) evalh_gates_kernel(ProgDev g, ColsDev c, Fe* values, Fe* gws, uint32_t lanes) {
+__global__ void __launch_bounds__(256) evalh_gates_kernel(ProgDev g, ColsDev c, Fe* values, Fu* gws, uint32_t lanes) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= lanes) return;
     Slots<MAXI> slots(gws + tid, lanes);
-    for (uint64_t idx = tid; idx < (1ull << c.log_size); idx += lanes) values[idx] = prog_eval(g, c, (uint32_t)idx, values[idx], slots);
+    for (uint64_t row = tid; row < (1ull << c.log_size); row += lanes) {
+        const uint32_t idx = (uint32_t)row;
+        const Fe prev = values[idx];
+        const Fu r = prog_eval(g, c, idx, ld_i(prev), slots);
+        values[idx] = prog_result_e<Slots<MAXI>>(g, c, idx, prev, r);
+    }
 }
 
 struct PermDev {
@@ -130,45 +173,49 @@ struct PermDev {
     const Fe* const* cols;    // the permuted columns' extended cosets, already resolved by (kind, index)
     const Fe* const* cosets;  // pk.permutation.cosets
     const Fe *l0, *l_last, *l_active;
-    Fe delta, delta_start;  // delta_start = beta * ZETA (:368)
-    const Fe* omega_pow2;   // [28] extended_omega^(2^j): extended_omega^idx is a product over the set bits of idx
+    Fu delta, delta_start;    // I-form canonical; delta_start = beta * ZETA (:368)
+    const Fu* omega_pow2;     // [28] extended_omega^(2^j), I-form canonical: extended_omega^idx is a product over the set bits of idx
     uint32_t n_sets, n_cols, chunk_len;
     int32_t last_rotation;
 };
 
+// Magnitudes in units of r are given in brackets.
 __global__ void __launch_bounds__(256) evalh_perm_kernel(PermDev p, ColsDev c, Fe* values) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (1u << c.log_size)) return;
-    const Fe one = fe_one<FrP>();
+    const Fu one = fu_one_i<UF>();
     const uint32_t r_next = rot_idx(idx, 1, c.rot_scale, c.log_size);
     const uint32_t r_last = rot_idx(idx, p.last_rotation, c.rot_scale, c.log_size);
-    Fe v = values[idx];
+    Fu v = ld_i(values[idx]);  // [32]
     // l_0(X) * (1 - z_0(X)) = 0                                                   :382-386
-    v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(fe_sub<FrP>(one, p.z[0][idx]), p.l0[idx]));
+    v = addn(mul_i(v, c.y), mul_i(subn(one, ld_i(p.z[0][idx])), ld_i(p.l0[idx])));  // [1.2] + [33 * 32 / 169 + 1 = 7.3] = [8.5]
     // l_last(X) * (z_l(X)^2 - z_l(X)) = 0                                         :387-393
     {
-        Fe zl = p.z[p.n_sets - 1][idx];
-        v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(fe_sub<FrP>(fe_sqr<FrP>(zl), zl), p.l_last[idx]));
+        const Fu zl = ld_i(p.z[p.n_sets - 1][idx]);                                          // [32]
+        v = addn(mul_i(v, c.y), mul_i(subn(fu_sqr<UF>(zl), zl), ld_i(p.l_last[idx])));      // [1.1] + [(7.1 + 32) * 32 / 169 + 1 = 8.4] = [9.5]
     }
     // l_0(X) * (z_i(X) - z_{i-1}(omega^(last) X)) = 0                              :394-404
     for (uint32_t s = 1; s < p.n_sets; s++)
-        v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(fe_sub<FrP>(p.z[s][idx], p.z[s - 1][r_last]), p.l0[idx]));
+        v = addn(mul_i(v, c.y), mul_i(subn(ld_i(p.z[s][idx]), ld_i(p.z[s - 1][r_last])), ld_i(p.l0[idx])));  // [1.1] + [64 * 32 / 169 + 1 = 13.2] = [14.3]
     // (1 - (l_last + l_blind)) * (z_i(wX) prod(p + beta s_j + gamma) - z_i(X) prod(p + delta^j beta X + gamma))   :405-438
-    Fe current_delta = p.delta_start;  // beta * ZETA * extended_omega^idx (beta_term, :366-368 and :412)
+    Fu current_delta = p.delta_start;  // beta * ZETA * extended_omega^idx (beta_term, :366-368 and :412)   [1 .. 2]
     for (uint32_t j = 0; j < c.log_size; j++)
-        if ((idx >> j) & 1) current_delta = fe_mul<FrP>(current_delta, p.omega_pow2[j]);
+        if ((idx >> j) & 1) current_delta = mul_i(current_delta, p.omega_pow2[j]);
     for (uint32_t s = 0; s < p.n_sets; s++) {
         const uint32_t j0 = s * p.chunk_len, j1 = j0 + p.chunk_len < p.n_cols ? j0 + p.chunk_len : p.n_cols;
-        Fe left = p.z[s][r_next], right = p.z[s][idx];
-        for (uint32_t j = j0; j < j1; j++)
-            left = fe_mul<FrP>(left, fe_add<FrP>(fe_add<FrP>(p.cols[j][idx], fe_mul<FrP>(c.beta, p.cosets[j][idx])), c.gamma));
+        Fu left = ld_i(p.z[s][r_next]), right = ld_i(p.z[s][idx]);  // [32]
         for (uint32_t j = j0; j < j1; j++) {
-            right = fe_mul<FrP>(right, fe_add<FrP>(fe_add<FrP>(p.cols[j][idx], current_delta), c.gamma));
-            current_delta = fe_mul<FrP>(current_delta, p.delta);
+            const Fu term = addn(addn(ld_i(p.cols[j][idx]), mul_i(c.beta, ld_i(p.cosets[j][idx]))), c.gamma);  // [32 + 1.2 + 1 = 34.2]
+            left = mul_i(left, term);                                                                          // [32 * 34.2 / 169 + 1 = 7.5], then smaller
         }
-        v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(fe_sub<FrP>(left, right), p.l_active[idx]));
+        for (uint32_t j = j0; j < j1; j++) {
+            const Fu term = addn(addn(ld_i(p.cols[j][idx]), current_delta), c.gamma);  // [35]
+            right = mul_i(right, term);                                                // [7.7]
+            current_delta = mul_i(current_delta, p.delta);                             // [1.1]
+        }
+        v = addn(mul_i(v, c.y), mul_i(subn(left, right), ld_i(p.l_active[idx])));     // [1.1] + [64 * 32 / 169 + 1 = 13.2] = [14.3]
     }
-    values[idx] = v;
+    values[idx] = out_e(v);  // [< 15]
 }
 
 struct LookupDev {
@@ -177,33 +224,34 @@ struct LookupDev {
 };
 
 template <int MAXI>
-__global__ void __launch_bounds__(256) evalh_lookup_kernel(ProgDev g, LookupDev l, ColsDev c, Fe* values, Fe* gws, uint32_t lanes) {
+__global__ void __launch_bounds__(256) evalh_lookup_kernel(ProgDev g, LookupDev l, ColsDev c, Fe* values, Fu* gws, uint32_t lanes) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= lanes) return;
     Slots<MAXI> slots(gws + tid, lanes);
-    const Fe one = fe_one<FrP>();
+    const Fu one = fu_one_i<UF>();
     for (uint64_t row = tid; row < (1ull << c.log_size); row += lanes) {
         const uint32_t idx = (uint32_t)row;
-        const Fe table_value = prog_eval(g, c, idx, fe_zero<FrP>(), slots);  // :466-480
+        const Fu table_value = prog_eval(g, c, idx, fu_zero(), slots);  // :466-480   [< 32]
         const uint32_t r_next = rot_idx(idx, 1, c.rot_scale, c.log_size), r_prev = rot_idx(idx, -1, c.rot_scale, c.log_size);
-        const Fe z = l.product[idx], a_ = l.pin[idx], s_ = l.ptab[idx];
-        const Fe a_minus_s = fe_sub<FrP>(a_, s_);
-        Fe v = values[idx];
+        const Fu z = ld_i(l.product[idx]), a_ = ld_i(l.pin[idx]), s_ = ld_i(l.ptab[idx]);  // [32]
+        const Fu l0 = ld_i(l.l0[idx]), l_active = ld_i(l.l_active[idx]);                  // [32]
+        const Fu a_minus_s = subn(a_, s_);                                                // [64]
+        Fu v = ld_i(values[idx]);                                                         // [32]
         // l_0(X) * (1 - z(X)) = 0
-        v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(fe_sub<FrP>(one, z), l.l0[idx]));
+        v = addn(mul_i(v, c.y), mul_i(subn(one, z), l0));                                             // [1.2 + 7.3 = 8.5]
         // l_last(X) * (z(X)^2 - z(X)) = 0
-        v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(fe_sub<FrP>(fe_sqr<FrP>(z), z), l.l_last[idx]));
+        v = addn(mul_i(v, c.y), mul_i(subn(fu_sqr<UF>(z), z), ld_i(l.l_last[idx])));                  // [1.1 + 8.4 = 9.5]
         // (1 - (l_last + l_blind)) * (z(wX)(a' + beta)(s' + gamma) - z(X) * table_value) = 0
         {
-            Fe lhs = fe_mul<FrP>(fe_mul<FrP>(l.product[r_next], fe_add<FrP>(a_, c.beta)), fe_add<FrP>(s_, c.gamma));
-            Fe rhs = fe_mul<FrP>(z, table_value);
-            v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(fe_sub<FrP>(lhs, rhs), l.l_active[idx]));
+            const Fu lhs = mul_i(mul_i(ld_i(l.product[r_next]), addn(a_, c.beta)), addn(s_, c.gamma));  // [32 * 33 / 169 + 1 = 7.3] -> [7.3 * 33 / 169 + 1 = 2.5]
+            const Fu rhs = mul_i(z, table_value);                                                       // [32 * 32 / 169 + 1 = 7.1]
+            v = addn(mul_i(v, c.y), mul_i(subn(lhs, rhs), l_active));                                   // [1.1] + [9.6 * 32 / 169 + 1 = 2.9] = [4]
         }
         // l_0(X) * (a'(X) - s'(X)) = 0
-        v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(a_minus_s, l.l0[idx]));
+        v = addn(mul_i(v, c.y), mul_i(a_minus_s, l0));                                                  // [1.1] + [64 * 32 / 169 + 1 = 13.2] = [14.3]
         // (1 - (l_last + l_blind)) * (a' - s') * (a'(X) - a'(w^-1 X)) = 0
-        v = fe_add<FrP>(fe_mul<FrP>(v, c.y), fe_mul<FrP>(fe_mul<FrP>(a_minus_s, fe_sub<FrP>(a_, l.pin[r_prev])), l.l_active[idx]));
-        values[idx] = v;
+        v = addn(mul_i(v, c.y), mul_i(mul_i(a_minus_s, subn(a_, ld_i(l.pin[r_prev]))), l_active));      // [1.1] + [(64 * 64 / 169 + 1 = 25.3) * 32 / 169 + 1 = 5.8] = [6.9]
+        values[idx] = out_e(v);
     }
 }
 
@@ -214,6 +262,14 @@ static inline Fe load_fe(const uint64_t* v) {
     Fe o;
     memcpy(o.l, v, sizeof(o.l));
     return o;
+}
+
+// E-form canonical element -> I-form canonical limbs (x * 2^5 mod r, sliced): how constants, challenges and the
+// y / beta / gamma / theta scalars enter the kernels
+static inline Fu to_i(const Fe& x) {
+    Fe t = x;
+    for (int k = 0; k < 5; k++) t = fe_dbl<FrP>(t);
+    return fu_slice(t);
 }
 
 static bool vs_ok(const h2hip_value_source& v, const h2hip_graph& g, const h2hip_evalh_desc& d) {
@@ -346,6 +402,17 @@ static Program compile_graph(const h2hip_graph& g) {
         }
         if (result.kind == H2HIP_VS_INTERMEDIATE) last_use[result.a] = never;
     }
+    // 4. magnitudes (see the comment at DevOp): walked with the slots, a reduction is requested wherever a sum would
+    //    pass EVALH_MAG_LIMIT, and the result is brought below EVALH_MAG_RESULT for the exact final reduction
+    std::vector<double> slot_mag;
+    auto mag = [&](const h2hip_value_source& v) -> double {
+        switch (v.kind) {
+            case H2HIP_VS_INTERMEDIATE: return slot_mag[v.a];
+            case H2HIP_VS_FIXED: case H2HIP_VS_ADVICE: case H2HIP_VS_INSTANCE: case H2HIP_VS_PREVIOUS: return EVALH_MAG_COLUMN;
+            case EVALH_VS_ZERO: return 0.0;
+            default: return 1.0;  // constants, challenges, beta / gamma / theta / y: canonical
+        }
+    };
     std::vector<uint32_t> free_slots;
     uint32_t pos = 0;
     for (size_t i = 0; i < ops.size(); i++) {
@@ -355,6 +422,7 @@ static Program compile_graph(const h2hip_graph& g) {
         const uint32_t xv = o.x.a, yv = o.y.a;
         if (xi) o.x.a = slot[xv];
         if (yi) o.y.a = slot[yv];
+        const double mx = mag(o.x), my = mag(o.y), md = (o.op == OP_FMA) ? slot_mag[slot[o.dst]] : 0.0;
         if (xi && last_use[xv] == pos) free_slots.push_back(slot[xv]);
         if (yi && last_use[yv] == pos && !(xi && yv == xv)) free_slots.push_back(slot[yv]);
         if (slot[o.dst] == never) {  // a definition (FMA steps reuse the slot their MOV took)
@@ -366,10 +434,28 @@ static Program compile_graph(const h2hip_graph& g) {
             }
         }
         o.dst = slot[o.dst];
+        if (slot_mag.size() < P.n_slots) slot_mag.resize(P.n_slots, 0.0);
+        double m;
+        switch (o.op) {
+            case OP_ADD: case OP_SUB: m = mx + my; break;
+            case OP_MUL: m = mx * my / 169.0 + 1.0; break;
+            case OP_SQR: m = mx * mx / 169.0 + 1.0; break;
+            case OP_DBL: m = 2.0 * mx; break;
+            case OP_FMA: m = md * my / 169.0 + 1.0 + mx; break;
+            default: m = mx;  // NEG, MOV
+        }
+        if (m > EVALH_MAG_LIMIT) {
+            o.op |= OP_REDUCE_FLAG;
+            m = m / 169.0 + 1.0;
+        }
+        slot_mag[o.dst] = m;
         P.ops.push_back(o);
         pos++;
     }
-    if (result.kind == H2HIP_VS_INTERMEDIATE) result.a = slot[result.a];
+    if (result.kind == H2HIP_VS_INTERMEDIATE) {
+        result.a = slot[result.a];
+        if (slot_mag[result.a] > EVALH_MAG_RESULT) P.ops.push_back({OP_MOV | OP_REDUCE_FLAG, result.a, result, none});
+    }
     P.result = result;
     return P;
 }
@@ -385,18 +471,22 @@ struct Arena {
 };
 
 static size_t prog_bytes(const h2hip_graph& g, const Program& P) {
-    return 3 * 256 + g.n_constants * sizeof(Fe) + g.n_rotations * 4 + P.ops.size() * sizeof(DevOp);
+    return 3 * 256 + g.n_constants * sizeof(Fu) + g.n_rotations * 4 + P.ops.size() * sizeof(DevOp);
 }
 
 static int prog_upload(Arena& ar, const h2hip_graph& g, const Program& P, ProgDev* out, hipStream_t s) {
-    Fe* dc = (Fe*)ar.take(g.n_constants * sizeof(Fe));
+    Fu* dc = (Fu*)ar.take(g.n_constants * sizeof(Fu));
     int32_t* dr = (int32_t*)ar.take(g.n_rotations * 4);
     DevOp* dq = (DevOp*)ar.take(P.ops.size() * sizeof(DevOp));
     if (!dc || !dr || !dq) {
         set_error("evaluate_h: arena overflow");
         return 1;
     }
-    if (g.n_constants) H2_CHECK(hipMemcpyAsync(dc, g.constants, g.n_constants * sizeof(Fe), hipMemcpyHostToDevice, s));
+    if (g.n_constants) {
+        std::vector<Fu> hc(g.n_constants);
+        for (uint32_t i = 0; i < g.n_constants; i++) hc[i] = to_i(load_fe(g.constants + 4 * (size_t)i));
+        H2_CHECK(hipMemcpyAsync(dc, hc.data(), hc.size() * sizeof(Fu), hipMemcpyHostToDevice, s));  // pageable: staged before return
+    }
     if (g.n_rotations) H2_CHECK(hipMemcpyAsync(dr, g.rotations, g.n_rotations * 4, hipMemcpyHostToDevice, s));
     if (!P.ops.empty()) H2_CHECK(hipMemcpyAsync(dq, P.ops.data(), P.ops.size() * sizeof(DevOp), hipMemcpyHostToDevice, s));
     out->constants = dc;
@@ -427,14 +517,14 @@ static int slot_plan(uint32_t n_slots, size_t size, SlotPlan* out) {
     }
     uint32_t lanes = all < 256u * 2048u ? all : 256u * 2048u;  // at most every wave slot of the chip
     const size_t budget = (size_t)32 << 30;
-    while ((size_t)n_slots * lanes * sizeof(Fe) > budget && lanes > 16384) lanes /= 2;
-    if ((size_t)n_slots * lanes * sizeof(Fe) > budget) {
+    while ((size_t)n_slots * lanes * sizeof(Fu) > budget && lanes > 16384) lanes /= 2;
+    if ((size_t)n_slots * lanes * sizeof(Fu) > budget) {
         set_error("evaluate_h: a graph with %u simultaneously live intermediates does not fit this engine's workspace", n_slots);
         return H2HIP_ENOMEM;
     }
     out->tier = 0;
     out->lanes = lanes;
-    out->ws_bytes = (size_t)n_slots * lanes * sizeof(Fe);
+    out->ws_bytes = (size_t)n_slots * lanes * sizeof(Fu);
     return 0;
 }
 
@@ -520,12 +610,12 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         if ((rc = slot_plan(lookup_progs[i].n_slots, size, &lookup_plans[i]))) return rc;
         if (lookup_plans[i].ws_bytes > slots_ws) slots_ws = lookup_plans[i].ws_bytes;
     }
-    size_t need = n_cols * (col_bytes + 256) + 64 * 1024 + prog_bytes(d->custom_gates, gates_prog) + (size_t)d->n_challenges * sizeof(Fe) +
+    size_t need = n_cols * (col_bytes + 256) + 64 * 1024 + prog_bytes(d->custom_gates, gates_prog) + (size_t)d->n_challenges * sizeof(Fu) +
                   8 * ((size_t)d->n_fixed + d->n_advice + d->n_instance + d->n_perm_sets + 2 * (size_t)d->n_perm_columns + 16) + 4096;
     for (uint32_t i = 0; i < d->n_lookups; i++) need += prog_bytes(d->lookup_graphs[i], lookup_progs[i]);
     if ((rc = c->evalh_ws.ensure(need))) return rc;
     if (slots_ws && (rc = c->evalh_slots.ensure(slots_ws))) return rc;
-    Fe* const gws = (Fe*)c->evalh_slots.p;
+    Fu* const gws = (Fu*)c->evalh_slots.p;
     if ((rc = c->ws_acquire(s))) return rc;
     const hipMemcpyKind in_kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     Arena ar;
@@ -594,18 +684,22 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
     ColsDev cols;
     if ((rc = ptrs_upload(fixed, &cols.fixed)) || (rc = ptrs_upload(advice, &cols.advice)) || (rc = ptrs_upload(instance, &cols.instance))) return rc;
     {
-        Fe* dch = (Fe*)ar.take((d->n_challenges + 1) * sizeof(Fe));
+        Fu* dch = (Fu*)ar.take((d->n_challenges + 1) * sizeof(Fu));
         if (!dch) {
             set_error("evaluate_h: arena overflow");
             return 1;
         }
-        if (d->n_challenges) H2_CHECK(hipMemcpyAsync(dch, d->challenges, d->n_challenges * sizeof(Fe), hipMemcpyHostToDevice, s));
+        if (d->n_challenges) {
+            std::vector<Fu> hch(d->n_challenges);
+            for (uint32_t i = 0; i < d->n_challenges; i++) hch[i] = to_i(load_fe(d->challenges + 4 * (size_t)i));
+            H2_CHECK(hipMemcpyAsync(dch, hch.data(), hch.size() * sizeof(Fu), hipMemcpyHostToDevice, s));
+        }
         cols.challenges = dch;
     }
-    cols.beta = load_fe(d->beta);
-    cols.gamma = load_fe(d->gamma);
-    cols.theta = load_fe(d->theta);
-    cols.y = load_fe(d->y);
+    cols.beta = to_i(load_fe(d->beta));
+    cols.gamma = to_i(load_fe(d->gamma));
+    cols.theta = to_i(load_fe(d->theta));
+    cols.y = to_i(load_fe(d->y));
     cols.log_size = ek;
     cols.rot_scale = 1 << (ek - k);
     const dim3 grid((uint32_t)((size + 255) / 256)), block(256);
@@ -640,19 +734,22 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         pd.l_last = l_last;
         pd.l_active = l_active;
         {
-            Fe pw[28];
-            pw[0] = ext_omega;
-            for (int j = 1; j < 28; j++) pw[j] = fe_sqr<FrP>(pw[j - 1]);
-            Fe* d_pw = (Fe*)ar.take(sizeof(pw));
+            Fe pw = ext_omega;
+            Fu pwi[28];
+            for (int j = 0; j < 28; j++) {
+                pwi[j] = to_i(pw);
+                pw = fe_sqr<FrP>(pw);
+            }
+            Fu* d_pw = (Fu*)ar.take(sizeof(pwi));
             if (!d_pw) {
                 set_error("evaluate_h: arena overflow");
                 return 1;
             }
-            H2_CHECK(hipMemcpyAsync(d_pw, pw, sizeof(pw), hipMemcpyHostToDevice, s));
+            H2_CHECK(hipMemcpyAsync(d_pw, pwi, sizeof(pwi), hipMemcpyHostToDevice, s));
             pd.omega_pow2 = d_pw;
         }
-        pd.delta = load_fe(d->delta);
-        pd.delta_start = fe_mul<FrP>(cols.beta, load_fe(d->zeta));
+        pd.delta = to_i(load_fe(d->delta));
+        pd.delta_start = to_i(fe_mul<FrP>(load_fe(d->beta), load_fe(d->zeta)));
         pd.n_sets = d->n_perm_sets;
         pd.n_cols = d->n_perm_columns;
         pd.chunk_len = d->chunk_len;
