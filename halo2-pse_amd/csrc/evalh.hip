@@ -24,7 +24,7 @@ namespace h2 {
 // The flattened graph is compiled on the host (compile_graph below) into a short register-machine program before it is
 // run: Store calculations become direct column operands, a Horner calculation becomes one FMA per part placed as soon
 // as that part exists, dead calculations are dropped and the surviving intermediates are packed into as few slots as
-// their lifetimes allow.  A slot is 36 B of per-lane scratch (or, past 256 slots, a row of a global workspace), so a
+// their lifetimes allow.  A slot is 36 B of registers (up to 8 slots), per-lane scratch (up to 256) or a row of a global workspace, so a
 // circuit with tens of thousands of calculations still runs with a few dozen slots per lane.  The field operations
 // performed per row are the reference's, operation for operation; only where a value waits between them differs.
 //
@@ -68,6 +68,38 @@ struct ColsDev {
     int32_t rot_scale;
 };
 
+// Wave-uniform reads of data that no kernel writes (the program, its constants and rotations, the column pointer
+// tables): read through the constant address space so that they are scalar loads.  Through a generic pointer the
+// compiler must assume the kernel's own stores may alias them and issues one vector load per lane instead (measured:
+// 13 scalar against 1 900 vector memory instructions per wave in the gates kernel).
+#define H2_CONST_AS __attribute__((address_space(4)))
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ DevOp ld_op(const DevOp* ops, uint32_t q) {
+    const H2_CONST_AS u32x8* p = (const H2_CONST_AS u32x8*)(uintptr_t)ops;
+    const u32x8 w = p[q];
+    DevOp o;
+    o.op = w[0];
+    o.dst = w[1];
+    o.x.kind = w[2];
+    o.x.a = w[3];
+    o.x.b = w[4];
+    o.y.kind = w[5];
+    o.y.a = w[6];
+    o.y.b = w[7];
+    return o;
+}
+__device__ __forceinline__ Fu ld_const_fu(const Fu* tab, uint32_t i) {
+    const H2_CONST_AS int32_t* p = (const H2_CONST_AS int32_t*)(uintptr_t)tab;
+    Fu o;
+#pragma unroll
+    for (int k = 0; k < 9; k++) o.l[k] = p[9 * (size_t)i + k];
+    return o;
+}
+__device__ __forceinline__ int32_t ld_const_i32(const int32_t* tab, uint32_t i) { return ((const H2_CONST_AS int32_t*)(uintptr_t)tab)[i]; }
+__device__ __forceinline__ const Fe* ld_const_col(const Fe* const* tab, uint32_t i) {
+    return (const Fe*)(uintptr_t)((const H2_CONST_AS uint64_t*)(uintptr_t)tab)[i];
+}
+
 __device__ __forceinline__ Fu ld_i(const Fe& x) { return fu_from_ext(x); }                    // E canonical -> I, < 32 r
 __device__ __forceinline__ Fu addn(const Fu& a, const Fu& b) { return fu_norm(fu_add(a, b)); }
 __device__ __forceinline__ Fu subn(const Fu& a, const Fu& b) { return fu_norm(fu_sub(a, b)); }
@@ -81,6 +113,33 @@ struct Slots {
     __device__ __forceinline__ Slots(Fu*, size_t) {}
     __device__ __forceinline__ Fu get(uint32_t i) const { return v[i]; }
     __device__ __forceinline__ void set(uint32_t i, const Fu& x) { v[i] = x; }
+};
+// few slots (the common case: a gate polynomial is folded as soon as it exists): registers.  The slot index is
+// wave-uniform, so a chain of selects over constant indices keeps the array out of scratch.
+template <int N>
+struct RegSlots {
+    Fu v[N];
+    __device__ __forceinline__ RegSlots(Fu*, size_t) {}
+    __device__ __forceinline__ Fu get(uint32_t i) const {
+        Fu r = v[0];
+#pragma unroll
+        for (int k = 1; k < N; k++)
+            if (i == (uint32_t)k) r = v[k];
+        return r;
+    }
+    __device__ __forceinline__ void set(uint32_t i, const Fu& x) {
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            if (i == (uint32_t)k) v[k] = x;
+    }
+};
+template <>
+struct Slots<4> : RegSlots<4> {
+    __device__ __forceinline__ Slots(Fu* b, size_t s) : RegSlots<4>(b, s) {}
+};
+template <>
+struct Slots<8> : RegSlots<8> {
+    __device__ __forceinline__ Slots(Fu* b, size_t s) : RegSlots<8>(b, s) {}
 };
 template <>
 struct Slots<0> {
@@ -101,12 +160,12 @@ template <class S>
 __device__ __forceinline__ Fu vs_get(const ProgDev& g, const ColsDev& c, const h2hip_value_source& v, uint32_t idx, const S& slots,
                                      const Fu& previous) {
     switch (v.kind) {
-        case H2HIP_VS_CONSTANT: return g.constants[v.a];
+        case H2HIP_VS_CONSTANT: return ld_const_fu(g.constants, v.a);
         case H2HIP_VS_INTERMEDIATE: return slots.get(v.a);
-        case H2HIP_VS_FIXED: return ld_i(c.fixed[v.a][rot_idx(idx, g.rotations[v.b], c.rot_scale, c.log_size)]);
-        case H2HIP_VS_ADVICE: return ld_i(c.advice[v.a][rot_idx(idx, g.rotations[v.b], c.rot_scale, c.log_size)]);
-        case H2HIP_VS_INSTANCE: return ld_i(c.instance[v.a][rot_idx(idx, g.rotations[v.b], c.rot_scale, c.log_size)]);
-        case H2HIP_VS_CHALLENGE: return c.challenges[v.a];
+        case H2HIP_VS_FIXED: return ld_i(ld_const_col(c.fixed, v.a)[rot_idx(idx, ld_const_i32(g.rotations, v.b), c.rot_scale, c.log_size)]);
+        case H2HIP_VS_ADVICE: return ld_i(ld_const_col(c.advice, v.a)[rot_idx(idx, ld_const_i32(g.rotations, v.b), c.rot_scale, c.log_size)]);
+        case H2HIP_VS_INSTANCE: return ld_i(ld_const_col(c.instance, v.a)[rot_idx(idx, ld_const_i32(g.rotations, v.b), c.rot_scale, c.log_size)]);
+        case H2HIP_VS_CHALLENGE: return ld_const_fu(c.challenges, v.a);
         case H2HIP_VS_BETA: return c.beta;
         case H2HIP_VS_GAMMA: return c.gamma;
         case H2HIP_VS_THETA: return c.theta;
@@ -122,7 +181,7 @@ __device__ __forceinline__ Fu vs_get(const ProgDev& g, const ColsDev& c, const h
 template <class S>
 __device__ Fu prog_eval(const ProgDev& g, const ColsDev& c, uint32_t idx, const Fu& previous, S& slots) {
     for (uint32_t q = 0; q < g.n_ops; q++) {
-        const DevOp o = g.ops[q];
+        const DevOp o = ld_op(g.ops, q);
         const Fu a = vs_get(g, c, o.x, idx, slots, previous);
         Fu out;
         switch (o.op & 0xff) {
@@ -145,9 +204,9 @@ __device__ Fu prog_eval(const ProgDev& g, const ColsDev& c, uint32_t idx, const 
 template <class S>
 __device__ __forceinline__ Fe prog_result_e(const ProgDev& g, const ColsDev& c, uint32_t idx, const Fe& previous_e, const Fu& r) {
     switch (g.result.kind) {
-        case H2HIP_VS_FIXED: return c.fixed[g.result.a][rot_idx(idx, g.rotations[g.result.b], c.rot_scale, c.log_size)];
-        case H2HIP_VS_ADVICE: return c.advice[g.result.a][rot_idx(idx, g.rotations[g.result.b], c.rot_scale, c.log_size)];
-        case H2HIP_VS_INSTANCE: return c.instance[g.result.a][rot_idx(idx, g.rotations[g.result.b], c.rot_scale, c.log_size)];
+        case H2HIP_VS_FIXED: return ld_const_col(c.fixed, g.result.a)[rot_idx(idx, ld_const_i32(g.rotations, g.result.b), c.rot_scale, c.log_size)];
+        case H2HIP_VS_ADVICE: return ld_const_col(c.advice, g.result.a)[rot_idx(idx, ld_const_i32(g.rotations, g.result.b), c.rot_scale, c.log_size)];
+        case H2HIP_VS_INSTANCE: return ld_const_col(c.instance, g.result.a)[rot_idx(idx, ld_const_i32(g.rotations, g.result.b), c.rot_scale, c.log_size)];
         case H2HIP_VS_PREVIOUS: return previous_e;
         case EVALH_VS_ZERO: return fe_zero<FrP>();
         default: return out_e(r);
@@ -188,28 +247,29 @@ __global__ void __launch_bounds__(256) evalh_perm_kernel(PermDev p, ColsDev c, F
     const uint32_t r_last = rot_idx(idx, p.last_rotation, c.rot_scale, c.log_size);
     Fu v = ld_i(values[idx]);  // [32]
     // l_0(X) * (1 - z_0(X)) = 0                                                   :382-386
-    v = addn(mul_i(v, c.y), mul_i(subn(one, ld_i(p.z[0][idx])), ld_i(p.l0[idx])));  // [1.2] + [33 * 32 / 169 + 1 = 7.3] = [8.5]
+    v = addn(mul_i(v, c.y), mul_i(subn(one, ld_i(ld_const_col(p.z, 0)[idx])), ld_i(p.l0[idx])));  // [1.2] + [33 * 32 / 169 + 1 = 7.3] = [8.5]
     // l_last(X) * (z_l(X)^2 - z_l(X)) = 0                                         :387-393
     {
-        const Fu zl = ld_i(p.z[p.n_sets - 1][idx]);                                          // [32]
+        const Fu zl = ld_i(ld_const_col(p.z, p.n_sets - 1)[idx]);                                          // [32]
         v = addn(mul_i(v, c.y), mul_i(subn(fu_sqr<UF>(zl), zl), ld_i(p.l_last[idx])));      // [1.1] + [(7.1 + 32) * 32 / 169 + 1 = 8.4] = [9.5]
     }
     // l_0(X) * (z_i(X) - z_{i-1}(omega^(last) X)) = 0                              :394-404
     for (uint32_t s = 1; s < p.n_sets; s++)
-        v = addn(mul_i(v, c.y), mul_i(subn(ld_i(p.z[s][idx]), ld_i(p.z[s - 1][r_last])), ld_i(p.l0[idx])));  // [1.1] + [64 * 32 / 169 + 1 = 13.2] = [14.3]
+        v = addn(mul_i(v, c.y), mul_i(subn(ld_i(ld_const_col(p.z, s)[idx]), ld_i(ld_const_col(p.z, s - 1)[r_last])), ld_i(p.l0[idx])));  // [1.1] + [64 * 32 / 169 + 1 = 13.2] = [14.3]
     // (1 - (l_last + l_blind)) * (z_i(wX) prod(p + beta s_j + gamma) - z_i(X) prod(p + delta^j beta X + gamma))   :405-438
     Fu current_delta = p.delta_start;  // beta * ZETA * extended_omega^idx (beta_term, :366-368 and :412)   [1 .. 2]
     for (uint32_t j = 0; j < c.log_size; j++)
-        if ((idx >> j) & 1) current_delta = mul_i(current_delta, p.omega_pow2[j]);
+        if ((idx >> j) & 1) current_delta = mul_i(current_delta, ld_const_fu(p.omega_pow2, j));
     for (uint32_t s = 0; s < p.n_sets; s++) {
         const uint32_t j0 = s * p.chunk_len, j1 = j0 + p.chunk_len < p.n_cols ? j0 + p.chunk_len : p.n_cols;
-        Fu left = ld_i(p.z[s][r_next]), right = ld_i(p.z[s][idx]);  // [32]
+        const Fe* zs = ld_const_col(p.z, s);
+        Fu left = ld_i(zs[r_next]), right = ld_i(zs[idx]);  // [32]
         for (uint32_t j = j0; j < j1; j++) {
-            const Fu term = addn(addn(ld_i(p.cols[j][idx]), mul_i(c.beta, ld_i(p.cosets[j][idx]))), c.gamma);  // [32 + 1.2 + 1 = 34.2]
+            const Fu term = addn(addn(ld_i(ld_const_col(p.cols, j)[idx]), mul_i(c.beta, ld_i(ld_const_col(p.cosets, j)[idx]))), c.gamma);  // [32 + 1.2 + 1 = 34.2]
             left = mul_i(left, term);                                                                          // [32 * 34.2 / 169 + 1 = 7.5], then smaller
         }
         for (uint32_t j = j0; j < j1; j++) {
-            const Fu term = addn(addn(ld_i(p.cols[j][idx]), current_delta), c.gamma);  // [35]
+            const Fu term = addn(addn(ld_i(ld_const_col(p.cols, j)[idx]), current_delta), c.gamma);  // [35]
             right = mul_i(right, term);                                                // [7.7]
             current_delta = mul_i(current_delta, p.delta);                             // [1.1]
         }
@@ -500,7 +560,7 @@ static int prog_upload(Arena& ar, const h2hip_graph& g, const Program& P, ProgDe
 // Where the slots of a program live: per-lane scratch in three sizes, or (past 256) a global workspace of
 // n_slots x lanes elements with the rows taken grid-stride by `lanes` threads.
 struct SlotPlan {
-    int tier;        // 16, 64, 256 or 0 (global)
+    int tier;        // 4, 8 (registers), 16, 64, 256 (scratch) or 0 (global workspace)
     uint32_t lanes;  // threads launched
     size_t ws_bytes; // global workspace (tier 0)
 };
@@ -510,7 +570,7 @@ static uint32_t g_evalh_max_local_slots = 256;  // debug knob (tests force the g
 static int slot_plan(uint32_t n_slots, size_t size, SlotPlan* out) {
     const uint32_t all = (uint32_t)((size + 255) / 256 * 256);
     if (n_slots <= g_evalh_max_local_slots && n_slots <= 256) {
-        out->tier = n_slots <= 16 ? 16 : n_slots <= 64 ? 64 : 256;
+        out->tier = n_slots <= 4 ? 4 : n_slots <= 8 ? 8 : n_slots <= 16 ? 16 : n_slots <= 64 ? 64 : 256;
         out->lanes = all;
         out->ws_bytes = 0;
         return 0;
@@ -710,6 +770,8 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
     {
         const dim3 g(gates_plan.lanes / 256);
         switch (gates_plan.tier) {
+            case 4: hipLaunchKernelGGL(evalh_gates_kernel<4>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes); break;
+            case 8: hipLaunchKernelGGL(evalh_gates_kernel<8>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes); break;
             case 16: hipLaunchKernelGGL(evalh_gates_kernel<16>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes); break;
             case 64: hipLaunchKernelGGL(evalh_gates_kernel<64>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes); break;
             case 256: hipLaunchKernelGGL(evalh_gates_kernel<256>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes); break;
@@ -784,6 +846,8 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
             const SlotPlan& lp = lookup_plans[i];
             const dim3 g(lp.lanes / 256);
             switch (lp.tier) {
+                case 4: hipLaunchKernelGGL(evalh_lookup_kernel<4>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
+                case 8: hipLaunchKernelGGL(evalh_lookup_kernel<8>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
                 case 16: hipLaunchKernelGGL(evalh_lookup_kernel<16>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
                 case 64: hipLaunchKernelGGL(evalh_lookup_kernel<64>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
                 case 256: hipLaunchKernelGGL(evalh_lookup_kernel<256>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;

@@ -392,3 +392,21 @@ def test_gpu_evaluate_h_degenerate_systems(h2, oracle, variant):
     got = vin.copy()
     assert h2.lib().h2hip_evaluate_h_bn254(h.byref(), got.ctypes.data_as(ctypes.c_void_p)) == 0, h2.lib().h2hip_last_error()
     assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_live", [2, 6, 12, 40, 100])
+def test_gpu_evaluate_h_every_slot_tier(h2, oracle, n_live):
+    """slots live in registers (up to 4 / 8), per-lane scratch (16 / 64 / 256) or the global workspace: one graph per tier,
+    each with n_live products alive at once, against the oracle"""
+    from evalh_util import flatten_graph
+    case, vin = _random_case(oracle, 7, seed=50 + n_live)
+    case["custom"] = flatten_graph(_many_live_graph(n_live))
+    _, n_slots = _compile_stats(h2, case["custom"])
+    assert n_live <= n_slots <= n_live + 2
+    h = DescHolder(case)
+    want = vin.copy()
+    assert oracle.lib().oracle_evaluate_h(h.byref(), want.ctypes.data_as(ctypes.c_void_p)) == 0
+    got = vin.copy()
+    assert h2.lib().h2hip_evaluate_h_bn254(h.byref(), got.ctypes.data_as(ctypes.c_void_p)) == 0, h2.lib().h2hip_last_error()
+    assert np.array_equal(got, want)
