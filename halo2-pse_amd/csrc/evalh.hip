@@ -24,7 +24,7 @@ namespace h2 {
 // The flattened graph is compiled on the host (compile_graph below) into a short register-machine program before it is
 // run: Store calculations become direct column operands, a Horner calculation becomes one FMA per part placed as soon
 // as that part exists, dead calculations are dropped and the surviving intermediates are packed into as few slots as
-// their lifetimes allow.  A slot is 36 B of registers (up to 8 slots), per-lane scratch (up to 256) or a row of a global workspace, so a
+// their lifetimes allow.  A slot is 36 B of LDS (up to 8 slots), per-lane scratch (up to 256) or a row of a global workspace, so a
 // circuit with tens of thousands of calculations still runs with a few dozen slots per lane.  The field operations
 // performed per row are the reference's, operation for operation; only where a value waits between them differs.
 //
@@ -114,32 +114,31 @@ struct Slots {
     __device__ __forceinline__ Fu get(uint32_t i) const { return v[i]; }
     __device__ __forceinline__ void set(uint32_t i, const Fu& x) { v[i] = x; }
 };
-// few slots (the common case: a gate polynomial is folded as soon as it exists): registers.  The slot index is
-// wave-uniform, so a chain of selects over constant indices keeps the array out of scratch.
+// few slots (the common case: a gate polynomial is folded as soon as it exists): LDS, laid out [slot][limb][thread] so
+// that a wave's access is one conflict-free row.  (Registers would be better still, but the slot index is only known at
+// run time and LLVM turns any select chain over would-be register slots back into an indexed scratch access.)
+extern __shared__ int32_t evalh_lds[];
 template <int N>
-struct RegSlots {
-    Fu v[N];
-    __device__ __forceinline__ RegSlots(Fu*, size_t) {}
+struct LdsSlots {
+    __device__ __forceinline__ LdsSlots(Fu*, size_t) {}
     __device__ __forceinline__ Fu get(uint32_t i) const {
-        Fu r = v[0];
+        Fu r;
 #pragma unroll
-        for (int k = 1; k < N; k++)
-            if (i == (uint32_t)k) r = v[k];
+        for (int k = 0; k < 9; k++) r.l[k] = evalh_lds[(i * 9 + k) * 256 + threadIdx.x];
         return r;
     }
     __device__ __forceinline__ void set(uint32_t i, const Fu& x) {
 #pragma unroll
-        for (int k = 0; k < N; k++)
-            if (i == (uint32_t)k) v[k] = x;
+        for (int k = 0; k < 9; k++) evalh_lds[(i * 9 + k) * 256 + threadIdx.x] = x.l[k];
     }
 };
 template <>
-struct Slots<4> : RegSlots<4> {
-    __device__ __forceinline__ Slots(Fu* b, size_t s) : RegSlots<4>(b, s) {}
+struct Slots<4> : LdsSlots<4> {
+    __device__ __forceinline__ Slots(Fu* b, size_t s) : LdsSlots<4>(b, s) {}
 };
 template <>
-struct Slots<8> : RegSlots<8> {
-    __device__ __forceinline__ Slots(Fu* b, size_t s) : RegSlots<8>(b, s) {}
+struct Slots<8> : LdsSlots<8> {
+    __device__ __forceinline__ Slots(Fu* b, size_t s) : LdsSlots<8>(b, s) {}
 };
 template <>
 struct Slots<0> {
@@ -179,7 +178,7 @@ __device__ __forceinline__ Fu vs_get(const ProgDev& g, const ColsDev& c, const h
 // Returns the I-form result; the host guarantees its magnitude is below EVALH_MAG_RESULT when it is a slot (a column or a
 // constant can also be the result of a degenerate graph: < 32).
 template <class S>
-__device__ Fu prog_eval(const ProgDev& g, const ColsDev& c, uint32_t idx, const Fu& previous, S& slots) {
+__device__ __forceinline__ Fu prog_eval(const ProgDev& g, const ColsDev& c, uint32_t idx, const Fu& previous, S& slots) {
     for (uint32_t q = 0; q < g.n_ops; q++) {
         const DevOp o = ld_op(g.ops, q);
         const Fu a = vs_get(g, c, o.x, idx, slots, previous);
@@ -560,7 +559,7 @@ static int prog_upload(Arena& ar, const h2hip_graph& g, const Program& P, ProgDe
 // Where the slots of a program live: per-lane scratch in three sizes, or (past 256) a global workspace of
 // n_slots x lanes elements with the rows taken grid-stride by `lanes` threads.
 struct SlotPlan {
-    int tier;        // 4, 8 (registers), 16, 64, 256 (scratch) or 0 (global workspace)
+    int tier;        // 4, 8 (LDS), 16, 64, 256 (scratch) or 0 (global workspace)
     uint32_t lanes;  // threads launched
     size_t ws_bytes; // global workspace (tier 0)
 };
@@ -770,8 +769,8 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
     {
         const dim3 g(gates_plan.lanes / 256);
         switch (gates_plan.tier) {
-            case 4: hipLaunchKernelGGL(evalh_gates_kernel<4>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes); break;
-            case 8: hipLaunchKernelGGL(evalh_gates_kernel<8>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes); break;
+            case 4: hipLaunchKernelGGL(evalh_gates_kernel<4>, g, block, 4 * 9 * 256 * 4, s, gd, cols, d_values, gws, gates_plan.lanes); break;
+            case 8: hipLaunchKernelGGL(evalh_gates_kernel<8>, g, block, 8 * 9 * 256 * 4, s, gd, cols, d_values, gws, gates_plan.lanes); break;
             case 16: hipLaunchKernelGGL(evalh_gates_kernel<16>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes); break;
             case 64: hipLaunchKernelGGL(evalh_gates_kernel<64>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes); break;
             case 256: hipLaunchKernelGGL(evalh_gates_kernel<256>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes); break;
@@ -846,8 +845,8 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
             const SlotPlan& lp = lookup_plans[i];
             const dim3 g(lp.lanes / 256);
             switch (lp.tier) {
-                case 4: hipLaunchKernelGGL(evalh_lookup_kernel<4>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
-                case 8: hipLaunchKernelGGL(evalh_lookup_kernel<8>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
+                case 4: hipLaunchKernelGGL(evalh_lookup_kernel<4>, g, block, 4 * 9 * 256 * 4, s, lg, ld, cols, d_values, gws, lp.lanes); break;
+                case 8: hipLaunchKernelGGL(evalh_lookup_kernel<8>, g, block, 8 * 9 * 256 * 4, s, lg, ld, cols, d_values, gws, lp.lanes); break;
                 case 16: hipLaunchKernelGGL(evalh_lookup_kernel<16>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
                 case 64: hipLaunchKernelGGL(evalh_lookup_kernel<64>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
                 case 256: hipLaunchKernelGGL(evalh_lookup_kernel<256>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
