@@ -6,7 +6,7 @@
 // the reference's iterative form (arithmetic.rs:202-230: bit-reversal, then chunks 2, 4, ... n with
 // twiddles[i * twiddle_chunk]).  Between layers the points are brought back to affine by a batched inversion so that
 // every addition inside the scalar ladder is a mixed addition (9.2 vs 14 multiplications):
-//   ecfft_layer_kernel      t = [w] b by MSB-first double-and-add in the unsaturated XYZZ arithmetic of ecu.cuh (the
+//   ecfft_layer_kernel      t = [w] b by fixed 4-bit windows in the unsaturated XYZZ arithmetic of ecu.cuh (the
 //                           MSM's), the two closing additions in canonical ec.cuh arithmetic; layer 0 applies the
 //                           bit-reversal on its loads; butterflies with w = 1 skip the ladder (arithmetic.rs:255-260)
 //   ec_normalize_kernel     XYZZ -> affine, Montgomery's trick over 8 points per lane
@@ -23,8 +23,33 @@ struct Scalar256 {
     uint32_t w[8];  // canonical integer, little-endian
 };
 
-// acc = [e] p for an affine p (E-form), e a canonical 254-bit integer
+// acc = [e] p for an affine p (E-form), e a canonical 254-bit integer: fixed 4-bit windows, MSB first.  The table
+// [1..15] p lives in per-lane scratch as XYZZ points (the digit differs per lane); per window 4 doublings and one
+// general addition -- 64 additions instead of the ~254 a wave of lanes with unrelated scalars executes under
+// double-and-add (every bit position has some lane with a one).
 __device__ XYZZu ec_mul_affine(const Affine& p, const Scalar256& e) {
+    if (affine_is_identity(p)) return xyzzu_identity();
+    const Fu px = fu_from_ext(p.x), py = fu_from_ext(p.y);
+    XYZZu tab[16];
+    tab[0] = xyzzu_identity();
+    tab[1] = xyzzu_identity();
+    xyzzu_add_mixed<QU>(tab[1], px, py);
+    tab[2] = xyzzu_double_affine<QU>(px, py);
+    for (int j = 3; j < 16; j++) {
+        tab[j] = tab[j - 1];
+        xyzzu_add_mixed<QU>(tab[j], px, py);
+    }
+    XYZZu acc = tab[e.w[7] >> 28];  // e < 2^254: the top nibble is at most 3
+    for (int i = 62; i >= 0; i--) {
+        acc = xyzzu_double(xyzzu_double(xyzzu_double(xyzzu_double(acc))));
+        const uint32_t d = (e.w[i >> 3] >> ((i & 7) * 4)) & 15;
+        if (d) xyzzu_add(acc, tab[d]);
+    }
+    return acc;
+}
+
+// the same for a wave-uniform scalar (the final [1/n]): plain double-and-add with mixed additions, no divergence
+__device__ XYZZu ec_mul_affine_uniform(const Affine& p, const Scalar256& e) {
     XYZZu acc = xyzzu_identity();
     if (affine_is_identity(p)) return acc;
     const Fu px = fu_from_ext(p.x), py = fu_from_ext(p.y);
@@ -73,7 +98,7 @@ __global__ void __launch_bounds__(256) ecfft_layer_kernel(EcfftLayer L) {
 __global__ void __launch_bounds__(256) ec_scale_kernel(const Affine* in, XYZZ* out, uint64_t n, Scalar256 e) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= n) return;
-    out[tid] = xyzzu_to_ext(ec_mul_affine(in[tid], e));
+    out[tid] = xyzzu_to_ext(ec_mul_affine_uniform(in[tid], e));
 }
 
 #define EC_NORM_CHUNK 8
