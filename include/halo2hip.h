@@ -252,10 +252,23 @@ int h2hip_set_msm_window(uint32_t c);
 /* window width the engine would use for n pairs */
 uint32_t h2hip_get_msm_window(size_t n);
 /* Per-stage HIP-event timers recorded on the stream each kernel group is launched on.
- * Stages: "ntt", "msm_total", "msm_digits", "msm_sort", "msm_accum", "msm_heavy", "msm_reduce". */
+ * Stages: "ntt", "msm_total", "msm_digits", "msm_sort", "msm_accum", "msm_heavy", "msm_reduce", "g_to_lagrange". */
 int h2hip_profile_enable(int on);
 int h2hip_profile_reset(void);
 int h2hip_profile_get(const char* stage, double* total_ms, uint64_t* count);
+
+/* ---- test and tuning hooks (not part of the drop-in surface; used by tests/ and tools/ only) ---- */
+
+/* split MSM inputs above m pairs into consecutive chunks (default 2^26, the 31-bit pair-index limit; 0 restores it) */
+int h2hip_debug_set_msm_max_chunk(size_t m);
+/* CUs reserved for the sort / reduce streams of a batched MSM (0 = none: every split measured slower) */
+int h2hip_debug_set_reserved_cus(uint32_t k);
+/* largest log2 tile of an NTT pass (4..10; default 8, 9 beyond 2^24 points) */
+int h2hip_debug_set_ntt_smax(uint32_t v);
+/* evaluate_h: programs needing more slots than v use the global-workspace form of the kernels (default 256) */
+int h2hip_debug_set_evalh_max_local_slots(uint32_t v);
+/* evaluate_h: compile a graph as the engine would and report the program's size; needs no GPU */
+int h2hip_debug_evalh_compile_stats(const h2hip_graph* g, uint32_t* n_ops, uint32_t* n_slots);
 
 #ifdef __cplusplus
 }
