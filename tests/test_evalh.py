@@ -410,3 +410,78 @@ def test_gpu_evaluate_h_every_slot_tier(h2, oracle, n_live):
     got = vin.copy()
     assert h2.lib().h2hip_evaluate_h_bn254(h.byref(), got.ctypes.data_as(ctypes.c_void_p)) == 0, h2.lib().h2hip_last_error()
     assert np.array_equal(got, want)
+
+
+def _random_graph(rng, n_calcs, n_adv=5, n_fix=6):
+    """a random single-assignment graph straight in calculation form (not via add_expression): every operation kind, operands
+    drawn from columns / constants / challenges / earlier intermediates / beta-gamma-theta-y / PreviousValue, Store chains,
+    dead calculations, Horners with 0..6 parts anywhere in the graph, long runs of additions of un-reduced column values"""
+    from evalh_util import (CALC_ADD, CALC_DOUBLE, CALC_HORNER, CALC_MUL, CALC_NEGATE, CALC_SQUARE, CALC_STORE, CALC_SUB, GraphEvaluator,
+                            VS_ADVICE, VS_BETA, VS_CHALLENGE, VS_CONSTANT, VS_FIXED, VS_GAMMA, VS_INSTANCE, VS_INTERMEDIATE, VS_PREVIOUS, VS_THETA,
+                            VS_Y)
+    g = GraphEvaluator()
+    for r in (0, 1, -1, 2, -3):
+        g.add_rotation(r)
+    for _ in range(4):
+        g.add_constant(int(rng.integers(0, 1 << 62)) ** 3)
+    targets = []
+
+    def src():
+        kind = int(rng.integers(0, 10))
+        if kind <= 3 and targets:
+            return (VS_INTERMEDIATE, targets[int(rng.integers(0, len(targets)))], 0)
+        if kind <= 5:
+            return (VS_ADVICE, int(rng.integers(0, n_adv)), int(rng.integers(0, 5)))
+        if kind == 6:
+            return (VS_FIXED, int(rng.integers(0, n_fix)), int(rng.integers(0, 5)))
+        if kind == 7:
+            return (VS_CONSTANT, int(rng.integers(0, len(g.constants))), 0)
+        if kind == 8:
+            return [(VS_INSTANCE, 0, int(rng.integers(0, 5))), (VS_CHALLENGE, int(rng.integers(0, 2)), 0), (VS_PREVIOUS, 0, 0)][int(rng.integers(0, 3))]
+        return [(VS_BETA, 0, 0), (VS_GAMMA, 0, 0), (VS_THETA, 0, 0), (VS_Y, 0, 0)][int(rng.integers(0, 4))]
+
+    def emit(calc):
+        t = g.num_intermediates
+        g.calculations.append((calc, t))  # no deduplication: repeated calculations are legal input too
+        g.num_intermediates += 1
+        targets.append(t)
+
+    for _ in range(n_calcs):
+        op = [CALC_ADD, CALC_ADD, CALC_SUB, CALC_MUL, CALC_MUL, CALC_SQUARE, CALC_DOUBLE, CALC_NEGATE, CALC_HORNER, CALC_STORE][int(rng.integers(0, 10))]
+        if op in (CALC_ADD, CALC_SUB, CALC_MUL):
+            emit((op, src(), src(), ()))
+        elif op == CALC_HORNER:
+            emit((op, src(), src(), tuple(src() for _ in range(int(rng.integers(0, 7))))))
+        else:
+            emit((op, src(), None, ()))
+    return g
+
+
+def test_compile_survives_random_graphs(h2):
+    """host-only: validation + compilation of 200 random graphs neither fails nor needs more slots than intermediates"""
+    from evalh_util import flatten_graph
+    rng = np.random.default_rng(2024)
+    for i in range(200):
+        g = flatten_graph(_random_graph(rng, int(rng.integers(1, 120))))
+        n_ops, n_slots = _compile_stats(h2, g)
+        assert n_slots <= g["num_intermediates"] and n_ops <= g["calcs"].shape[0] + g["parts"].shape[0] + 2
+
+
+@pytest.mark.gpu
+def test_gpu_evaluate_h_random_graphs(h2, oracle):
+    """40 random graphs (custom gates and one lookup each) against the oracle: exercises Store folding, Horner hoisting, dead
+    code, slot reuse and the inserted magnitude reductions far from the shapes add_expression produces"""
+    from evalh_util import flatten_graph
+    rng = np.random.default_rng(77)
+    case, vin = _random_case(oracle, 5, seed=123)
+    for i in range(40):
+        case["custom"] = flatten_graph(_random_graph(rng, int(rng.integers(1, 90))))
+        lk = list(case["lookups"][0])
+        lk[0] = flatten_graph(_random_graph(rng, int(rng.integers(1, 40))))
+        case["lookups"] = [tuple(lk), case["lookups"][1]]
+        h = DescHolder(case)
+        want = vin.copy()
+        assert oracle.lib().oracle_evaluate_h(h.byref(), want.ctypes.data_as(ctypes.c_void_p)) == 0
+        got = vin.copy()
+        assert h2.lib().h2hip_evaluate_h_bn254(h.byref(), got.ctypes.data_as(ctypes.c_void_p)) == 0, h2.lib().h2hip_last_error()
+        assert np.array_equal(got, want), "graph %d" % i
