@@ -888,6 +888,12 @@ int h2hip_debug_evalh_compile_stats(const h2hip_graph* g, uint32_t* n_ops, uint3
     return evalh_debug_compile_stats(g, n_ops, n_slots);
 }
 
+// test / tuning hook: batches of small MSMs run fused (default) or pipelined over streams
+int h2hip_debug_set_msm_fuse_small(int on) {
+    msm_set_fuse_small(on != 0);
+    return 0;
+}
+
 int h2hip_debug_set_ntt_smax(uint32_t v) {
     ntt_set_smax(v);
     return 0;

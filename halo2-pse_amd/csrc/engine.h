@@ -133,6 +133,7 @@ int evaluate_h_validate(const h2hip_evalh_desc* d, const void* values);
 int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool dev, hipStream_t s);
 
 // msm.hip
+void msm_set_fuse_small(bool on);
 int msm_device(Ctx* c, const Fe* d_scalars, const Affine* d_bases, size_t n, XYZZ* h_out, hipStream_t s);
 int msm_batch_device(Ctx* c, const Fe* const* scalars, bool scalars_on_host, const Affine* d_bases, size_t n, size_t count, XYZZ* h_out,
                      hipStream_t s);

@@ -48,10 +48,13 @@ __device__ __forceinline__ uint32_t scalar_bits(const Fe& s, uint32_t bit, uint3
 }
 
 // K1: one lane per scalar
-__global__ void __launch_bounds__(256) msm_digits_kernel(const Fe* __restrict__ scalars, uint32_t n, uint32_t c, uint32_t W,
-                                                         uint32_t NB, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+// A fused batch launches it once with gridDim.y = MSMs: MSM y reads list[y] and writes windows [y * W, (y + 1) * W).
+__global__ void __launch_bounds__(256) msm_digits_kernel(const Fe* __restrict__ scalars_one, const Fe* const* __restrict__ list, uint32_t n, uint32_t c,
+                                                         uint32_t W, uint32_t NB, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const Fe* __restrict__ scalars = list ? list[blockIdx.y] : scalars_one;
+    const uint32_t w_base = blockIdx.y * W;
     Fe s = fe_to_canonical<FrP>(scalars[i]);
     uint32_t carry = 0;
     const uint32_t half = 1u << (c - 1);
@@ -66,8 +69,8 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const Fe* __restrict__ 
             neg = 1;
             carry = 1;
         }
-        size_t e = (size_t)w * n + i;
-        keys[e] = (w << c) | (d ? d - 1 : NB);
+        size_t e = (size_t)(w_base + w) * n + i;
+        keys[e] = ((w_base + w) << c) | (d ? d - 1 : NB);
         vals[e] = i | (neg << 31);
     }
 }
@@ -263,33 +266,50 @@ struct DigitPlan {
     uint32_t shift[8];   // bit position of digit d
 };
 
-// grid = W * (D + 1) * 32 single-wave workgroups (a 64-lane tree wastes fewer issue slots than a 256-lane
-// one: a wave executes an EC add at full cost however few of its lanes are active); T laid out [w][d][v]
+// T laid out [w][d][v].  LPT = 64: one single-wave workgroup per T (a 64-lane tree wastes fewer issue slots than a 256-lane
+// one: a wave executes an EC add at full cost however few of its lanes are active) -- the shortest chain, for a lone MSM.
+// LPT = 16: four T's per wave, 16 lanes each: longer per-lane sums, a 4-level tree -- a third of the wave-additions, for fused
+// batches, where there are tens of thousands of T's and the kernel is throughput-bound.  grid = ceil(W * (D + 1) * 32 * LPT / 64).
+template <int LPT>
 __global__ void __launch_bounds__(64) msm_reduce2_kernel(const XYZZu* __restrict__ acc_in, const XYZZu* __restrict__ run_in, uint32_t m1,
-                                                         DigitPlan dp, XYZZu* __restrict__ T) {
+                                                         DigitPlan dp, uint32_t n_T, XYZZu* __restrict__ T) {
     __shared__ XYZZu sh[64];
     const uint32_t D = dp.D;
-    const uint32_t v = blockIdx.x & 31;
-    const uint32_t d = (blockIdx.x >> 5) % (D + 1);
-    const uint32_t w = (blockIdx.x >> 5) / (D + 1);
+    const uint32_t sub = threadIdx.x % LPT;
+    const uint32_t ti = blockIdx.x * (64 / LPT) + threadIdx.x / LPT;  // which T this lane works for
+    const bool live = ti < n_T;
+    const uint32_t v = ti & 31;
+    const uint32_t d = (ti >> 5) % (D + 1);
+    const uint32_t w = (ti >> 5) / (D + 1);
     XYZZu acc = xyzzu_identity();
-    if (d == D) {
+    if (!live) {
+    } else if (d == D) {
         // plain sum of ACC[t] over t == v (mod 32)
         const XYZZu* A = acc_in + (size_t)w * m1;
-        for (uint32_t t = v + 32 * threadIdx.x; t < m1; t += 32 * blockDim.x) xyzzu_add(acc, A[t]);
+        for (uint32_t t = v + 32 * sub; t < m1; t += 32 * LPT) xyzzu_add(acc, A[t]);
     } else if (v < (1u << dp.width[d])) {
         // RUN[t] over the t whose digit d is v: t = hi << (shift + width) | v << shift | lo
         const XYZZu* Rn = run_in + (size_t)w * m1;
         const uint32_t sh_d = dp.shift[d], wd = dp.width[d];
         const uint32_t n_sel = (((m1 - 1) >> (sh_d + wd)) + 1) << sh_d;  // (hi, lo) combinations that can land below m1
-        for (uint32_t q = threadIdx.x; q < n_sel; q += blockDim.x) {
+        for (uint32_t q = sub; q < n_sel; q += LPT) {
             uint32_t lo = q & ((1u << sh_d) - 1), hi = q >> sh_d;
             uint32_t t = (hi << (sh_d + wd)) | (v << sh_d) | lo;
             if (t < m1) xyzzu_add(acc, Rn[t]);
         }
     }
-    XYZZu r = block_tree_sum(acc, sh);
-    if (threadIdx.x == 0) T[((size_t)w * (D + 1) + d) * 32 + v] = r;
+    // tree over the LPT lanes of each group
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t stride = LPT >> 1; stride >= 1; stride >>= 1) {
+        if (sub < stride) {
+            XYZZu a = sh[threadIdx.x];
+            xyzzu_add(a, sh[threadIdx.x + stride]);
+            sh[threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
+    if (sub == 0 && live) T[ti] = sh[threadIdx.x];
 }
 
 // one workgroup of 256 per window: lane (d, v) scales T[d][v] by v << shift[d] (double-and-add), one tree over
@@ -319,7 +339,7 @@ void msm_set_reserved_cus(uint32_t k) { g_reserved_cus = k; }
 uint32_t msm_get_reserved_cus() { return g_reserved_cus; }
 void msm_set_window(uint32_t c) { g_window_override = c; }
 
-static MsmPlan make_plan(size_t n) {
+static MsmPlan make_plan(size_t n, bool fused = false) {
     MsmPlan p;
     uint32_t c;
     if (g_window_override) {
@@ -329,7 +349,10 @@ static MsmPlan make_plan(size_t n) {
         while (((size_t)1 << (lg + 1)) <= n) lg++;
         // enough buckets to fill 256 CUs, few enough that the reduction stays small, and 254 mod c large so
         // that the top window is not a handful of over-full buckets
-        if (lg <= 8) c = 7;
+        // a fused batch has count times the buckets for the same chain lengths: narrower windows pay (measured per MSM,
+        // 16 x 2^17: c = 13 0.42 ms, c = 15 0.47 ms; 16 x 2^13: c = 10 0.156, c = 13 0.183)
+        if (fused && lg >= 13 && lg <= 18) c = lg <= 13 ? 10 : lg <= 16 ? 12 : lg == 17 ? 13 : 14;
+        else if (lg <= 8) c = 7;
         else if (lg <= 12) c = 10;
         else if (lg <= 16) c = 13;
         else if (lg <= 19) c = 15;
@@ -367,6 +390,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 
 // Workspace layout of one in-flight MSM ("slot")
 struct MsmLayout {
+    uint32_t fuse, Wt;  // MSMs sharing this workspace as one run (1 normally) and their windows in total: fuse * p.W
     MsmPlan p;
     DigitPlan dplan;
     size_t n, E;
@@ -375,29 +399,35 @@ struct MsmLayout {
     int end_bit;
     size_t cub_bytes, max_chunks, max_heavy;
     size_t o_keys0, o_keys1, o_vals0, o_vals1, o_cub, o_start, o_end, o_counts, o_perm, o_hist, o_buckets, o_acc, o_run, o_wsum, o_T, o_hcnt,
-        o_hb, o_hc, o_hs, o_zero_end, total;
+        o_hb, o_hc, o_hs, o_zero_end, o_ptrs, total;
 };
 
-static int msm_layout(size_t n, hipStream_t s, MsmLayout* L) {
-    MsmPlan p = make_plan(n);
+static int msm_layout(size_t n, hipStream_t s, MsmLayout* L, uint32_t fuse = 1) {
+    MsmPlan p = make_plan(n, fuse > 1);
     L->p = p;
     L->n = n;
-    L->E = n * p.W;
+    L->fuse = fuse;
+    L->Wt = p.W * fuse;
+    L->E = n * L->Wt;
     if (L->E >= ((size_t)1 << 31)) {
         set_error("msm: n*W = %zu pairs exceeds the 2^31 sort limit (window override too small?)", L->E);
         return 1;
     }
-    if (p.W > MSM_MAX_WINDOWS * 2) {
+    if (p.W > MSM_MAX_WINDOWS * 2 || L->Wt > 4096) {
         set_error("msm: too many windows");
         return 1;
     }
-    L->n_buckets = p.W * p.NB;
+    if ((uint64_t)L->Wt * p.NB >= (1ull << 31)) {
+        set_error("msm: too many buckets");
+        return 1;
+    }
+    L->n_buckets = L->Wt * p.NB;
     L->m1 = p.NB >> p.log_s1;
     // Small inputs: one radix sort over (window, slot); large inputs: one sort per window on the slot bits only
     // (the pairs are already window-major) -- 2 passes of 8 bits instead of 3 over all n*W pairs.
     L->per_window_sort = n >= ((size_t)1 << 22);
     uint32_t wbits = 0;
-    while ((1u << wbits) < p.W) wbits++;
+    while ((1u << wbits) < L->Wt) wbits++;
     L->end_bit = L->per_window_sort ? (int)p.c : (int)(p.c + wbits);
     L->cub_bytes = 0;
     H2_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, L->cub_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
@@ -433,19 +463,20 @@ static int msm_layout(size_t n, hipStream_t s, MsmLayout* L) {
     L->o_counts = carve((size_t)nb * 4);
     L->o_perm = carve((size_t)nb * 4);
     L->o_buckets = carve((size_t)nb * sizeof(XYZZu));
-    L->o_acc = carve((size_t)p.W * L->m1 * sizeof(XYZZu));
-    L->o_run = carve((size_t)p.W * L->m1 * sizeof(XYZZu));
-    L->o_wsum = carve((size_t)p.W * sizeof(XYZZ));
-    L->o_T = carve((size_t)p.W * (L->D + 1) * 32 * sizeof(XYZZu));
+    L->o_acc = carve((size_t)L->Wt * L->m1 * sizeof(XYZZu));
+    L->o_run = carve((size_t)L->Wt * L->m1 * sizeof(XYZZu));
+    L->o_wsum = carve((size_t)L->Wt * sizeof(XYZZ));
+    L->o_T = carve((size_t)L->Wt * (L->D + 1) * 32 * sizeof(XYZZu));
     L->o_hb = carve(L->max_heavy * sizeof(HeavyBucket));
     L->o_hc = carve(L->max_chunks * sizeof(HeavyChunk));
     L->o_hs = carve(L->max_chunks * sizeof(XYZZu));
+    L->o_ptrs = carve((size_t)fuse * sizeof(void*));
     L->total = off;
     return 0;
 }
 
 // stage A (memory-bound): digits, radix sort, bucket bounds, size order
-static int msm_stage_a(Ctx* c, const MsmLayout& L, char* base, const Fe* d_scalars, hipStream_t s) {
+static int msm_stage_a(Ctx* c, const MsmLayout& L, char* base, const Fe* const* d_scalars_list, hipStream_t s) {
     const MsmPlan& p = L.p;
     const size_t n = L.n;
     uint32_t *keys0 = (uint32_t*)(base + L.o_keys0), *keys1 = (uint32_t*)(base + L.o_keys1);
@@ -454,12 +485,18 @@ static int msm_stage_a(Ctx* c, const MsmLayout& L, char* base, const Fe* d_scala
     uint32_t *counts = (uint32_t*)(base + L.o_counts), *perm = (uint32_t*)(base + L.o_perm), *hist = (uint32_t*)(base + L.o_hist);
     int t0 = c->timer_begin("msm_digits", s);
     H2_CHECK(hipMemsetAsync(start, 0, L.o_zero_end - L.o_start, s));  // start[], end[], hist[], heavy counters
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, d_scalars, (uint32_t)n, p.c, p.W, p.NB, keys0, vals0);
+    const Fe* const* d_list = nullptr;
+    if (L.fuse > 1) {  // the scalar arrays' addresses, read by the kernel per blockIdx.y
+        H2_CHECK(hipMemcpyAsync(base + L.o_ptrs, d_scalars_list, L.fuse * sizeof(void*), hipMemcpyHostToDevice, s));  // pageable: staged before return
+        d_list = (const Fe* const*)(base + L.o_ptrs);
+    }
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256), L.fuse), dim3(256), 0, s, d_scalars_list[0], d_list, (uint32_t)n, p.c, p.W, p.NB,
+                       keys0, vals0);
     H2_CHECK(hipGetLastError());
     c->timer_end(t0, s);
     int t1 = c->timer_begin("msm_sort", s);
     if (L.per_window_sort) {
-        for (uint32_t w = 0; w < p.W; w++)
+        for (uint32_t w = 0; w < L.Wt; w++)
             H2_CHECK(hipcub::DeviceRadixSort::SortPairs(base + L.o_cub, const_cast<size_t&>(L.cub_bytes), keys0 + (size_t)w * n, keys1 + (size_t)w * n,
                                                         vals0 + (size_t)w * n, vals1 + (size_t)w * n, (int)n, 0, L.end_bit, s));
     } else {
@@ -512,15 +549,21 @@ static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_ws, hipSt
     XYZZu *accs = (XYZZu*)(base + L.o_acc), *runs = (XYZZu*)(base + L.o_run), *Tsum = (XYZZu*)(base + L.o_T);
     XYZZ* wsum = (XYZZ*)(base + L.o_wsum);
     int t4 = c->timer_begin("msm_reduce", s);
-    uint32_t n_seg = p.W * L.m1;
+    uint32_t n_seg = L.Wt * L.m1;
     hipLaunchKernelGGL(msm_reduce1_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, s, buckets, n_seg, p.log_s1, accs, runs);
     H2_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(msm_reduce2_kernel, dim3(p.W * (L.D + 1) * 32), dim3(64), 0, s, accs, runs, L.m1, L.dplan, Tsum);
+    {
+        const uint32_t n_T = L.Wt * (L.D + 1) * 32;
+        if (L.fuse > 1)
+            hipLaunchKernelGGL(msm_reduce2_kernel<16>, dim3((n_T + 3) / 4), dim3(64), 0, s, accs, runs, L.m1, L.dplan, n_T, Tsum);
+        else
+            hipLaunchKernelGGL(msm_reduce2_kernel<64>, dim3(n_T), dim3(64), 0, s, accs, runs, L.m1, L.dplan, n_T, Tsum);
+    }
     H2_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(msm_reduce3_kernel, dim3(p.W), dim3(256), 0, s, Tsum, L.dplan, p.log_s1, wsum);
+    hipLaunchKernelGGL(msm_reduce3_kernel, dim3(L.Wt), dim3(256), 0, s, Tsum, L.dplan, p.log_s1, wsum);
     H2_CHECK(hipGetLastError());
     c->timer_end(t4, s);
-    H2_CHECK(hipMemcpyAsync(h_ws, wsum, (size_t)p.W * sizeof(XYZZ), hipMemcpyDeviceToHost, s));
+    H2_CHECK(hipMemcpyAsync(h_ws, wsum, (size_t)L.Wt * sizeof(XYZZ), hipMemcpyDeviceToHost, s));
     return 0;
 }
 
@@ -567,7 +610,7 @@ static int msm_batch_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_h
         char* base = (char*)c->msm_slot[0].p;
         const Fe* sc;
         if ((rc = scalars_for(0, s, &sc))) return rc;
-        if ((rc = msm_stage_a(c, L, base, sc, s))) return rc;
+        if ((rc = msm_stage_a(c, L, base, &sc, s))) return rc;
         if ((rc = msm_stage_b(c, L, base, d_bases, s))) return rc;
         if ((rc = msm_stage_c(c, L, base, h_ws, s))) return rc;
     } else {
@@ -587,7 +630,7 @@ static int msm_batch_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_h
             if (j >= 3) H2_CHECK(hipStreamWaitEvent(a1, ev[3 + 3 * (j - 3)], 0));  // slot reuse: C(j-3) has drained it
             const Fe* sc;
             if ((rc = scalars_for(j, a1, &sc))) return rc;
-            if ((rc = msm_stage_a(c, L, base, sc, a1))) return rc;
+            if ((rc = msm_stage_a(c, L, base, &sc, a1))) return rc;
             H2_CHECK(hipEventRecord(ev[1 + 3 * j], a1));
             H2_CHECK(hipStreamWaitEvent(sb, ev[1 + 3 * j], 0));
             if ((rc = msm_stage_b(c, L, base, d_bases, sb))) return rc;
@@ -604,6 +647,42 @@ static int msm_batch_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_h
     return c->ws_release(s);
 }
 
+// Small MSMs over the same bases, fused: the `count` MSMs run as ONE pass of the three stages whose windows are the
+// windows of all of them (window j * W + w of the run is window w of MSM j).  The bucket reduction is a chain of ~60
+// dependent EC operations -- 0.43 ms whatever the size -- and dominates a 2^17-pair MSM; pipelining whole MSMs over streams
+// only overlaps those chains, fusing pays for one.  Sort and accumulate become one large launch each.
+static int msm_fused_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, const Affine* d_bases, size_t n, size_t count, XYZZ* h_out,
+                           hipStream_t s) {
+    MsmLayout L;
+    int rc = msm_layout(n, s, &L, (uint32_t)count);
+    if (rc) return rc;
+    if ((rc = c->msm_slot[0].ensure(L.total))) return rc;
+    std::vector<const Fe*> list(d_scalars, d_scalars + count);
+    if ((rc = c->ws_acquire(s))) return rc;
+    if (scalars_on_host) {
+        if ((rc = c->msm_scalars[0].ensure(count * n * sizeof(Fe)))) return rc;
+        for (size_t j = 0; j < count; j++) {
+            Fe* dst = (Fe*)c->msm_scalars[0].p + j * n;
+            H2_CHECK(hipMemcpyAsync(dst, d_scalars[j], n * sizeof(Fe), hipMemcpyHostToDevice, s));
+            list[j] = dst;
+        }
+    }
+    if ((rc = c->host_ws.ensure((size_t)L.Wt * sizeof(XYZZ)))) return rc;
+    XYZZ* h_ws = (XYZZ*)c->host_ws.p;
+    char* base = (char*)c->msm_slot[0].p;
+    int t_all = c->timer_begin("msm_total", s);
+    if ((rc = msm_stage_a(c, L, base, list.data(), s))) return rc;
+    if ((rc = msm_stage_b(c, L, base, d_bases, s))) return rc;
+    if ((rc = msm_stage_c(c, L, base, h_ws, s))) return rc;
+    c->timer_end(t_all, s);
+    H2_CHECK(hipStreamSynchronize(s));
+    for (size_t j = 0; j < count; j++) h_out[j] = combine_windows(h_ws + j * L.p.W, L.p);
+    return c->ws_release(s);
+}
+
+static bool g_fuse_small = true;
+void msm_set_fuse_small(bool on) { g_fuse_small = on; }
+
 // count MSMs over the same bases for device-resident inputs; results (XYZZ) to host memory.
 int msm_batch_device(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, const Affine* d_bases, size_t n, size_t count, XYZZ* h_out,
                      hipStream_t s) {
@@ -616,8 +695,19 @@ int msm_batch_device(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, c
     for (size_t o = 0; o < n; o += max_chunk) {
         size_t m = n - o < max_chunk ? n - o : max_chunk;
         for (size_t j = 0; j < count; j++) ptrs[j] = d_scalars[j] + o;
-        int rc = msm_batch_chunk(c, ptrs.data(), scalars_on_host, d_bases + o, m, count, part.data(), s);
-        if (rc) return rc;
+        // up to 2^18 pairs each: fused runs of at most 2^26 (pair, window) entries; larger MSMs: pipelined over streams
+        const size_t per_msm = m * make_plan(m, true).W;
+        const size_t fuse_max = per_msm ? ((size_t)1 << 26) / per_msm : 0;
+        if (g_fuse_small && count > 1 && m <= ((size_t)1 << 18) && fuse_max >= 2) {
+            for (size_t j0 = 0; j0 < count; j0 += fuse_max) {
+                const size_t g = count - j0 < fuse_max ? count - j0 : fuse_max;
+                int rc = msm_fused_chunk(c, ptrs.data() + j0, scalars_on_host, d_bases + o, m, g, part.data() + j0, s);
+                if (rc) return rc;
+            }
+        } else {
+            int rc = msm_batch_chunk(c, ptrs.data(), scalars_on_host, d_bases + o, m, count, part.data(), s);
+            if (rc) return rc;
+        }
         for (size_t j = 0; j < count; j++) xyzz_add(h_out[j], part[j]);
     }
     return 0;

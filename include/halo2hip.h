@@ -263,6 +263,8 @@ int h2hip_profile_get(const char* stage, double* total_ms, uint64_t* count);
 int h2hip_debug_set_msm_max_chunk(size_t m);
 /* CUs reserved for the sort / reduce streams of a batched MSM (0 = none: every split measured slower) */
 int h2hip_debug_set_reserved_cus(uint32_t k);
+/* batches of MSMs of up to 2^18 pairs: fused into one run (1, default) or pipelined over streams (0) */
+int h2hip_debug_set_msm_fuse_small(int on);
 /* largest log2 tile of an NTT pass (4..10; default 8, 9 beyond 2^24 points) */
 int h2hip_debug_set_ntt_smax(uint32_t v);
 /* evaluate_h: programs needing more slots than v use the global-workspace form of the kernels (default 256) */

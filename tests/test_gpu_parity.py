@@ -531,3 +531,33 @@ def test_batched_transforms_reject_bad_arguments(h2):
     assert L.h2hip_ntt_bn254_fr_batch_device(None, ctypes.c_size_t(2), one, ctypes.c_uint32(4), None) == 1
     assert L.h2hip_ntt_bn254_fr_batch_device(nul, ctypes.c_size_t(2), one, ctypes.c_uint32(29), None) == 1
     assert L.h2hip_coeff_to_extended_bn254_fr_batch_device(nul, ctypes.c_size_t(1), ctypes.c_uint32(5), ctypes.c_uint32(4), one, one, one, None) == 1
+
+
+def test_msm_batch_fused_equals_pipelined(h2, oracle):
+    """batches of small MSMs run as one fused pass over all their windows; with the fusion switched off the same batch goes
+    through the stream pipeline.  Both must give the same points as separate calls -- 16 columns of 2^15 + 3 pairs (dense and
+    prover-like, so over-full buckets too), and a batch larger than one fused run holds (2^18 pairs x 9)"""
+    import ctypes
+    L = h2.lib()
+    n = (1 << 15) + 3
+    dp = h2.gen_points_device(321, n)
+    dense = [h2.gen_scalars_device(700 + j, n) for j in range(12)]
+    import torch
+    sparse = [torch.from_numpy(_prover_like(oracle, n, 800 + j).view(np.int64)).cuda() for j in range(4)]
+    cols = dense + sparse
+    want = [aff(h2, h2.msm_device(c, dp)) for c in cols]
+    fused = h2.msm_batch_device(cols, dp)
+    try:
+        L.h2hip_debug_set_msm_fuse_small(0)
+        piped = h2.msm_batch_device(cols, dp)
+    finally:
+        L.h2hip_debug_set_msm_fuse_small(1)
+    for j in range(len(cols)):
+        assert np.array_equal(aff(h2, fused[j]), want[j]), j
+        assert np.array_equal(aff(h2, piped[j]), want[j]), j
+    n = 1 << 18
+    dp = h2.gen_points_device(322, n)
+    cols = [h2.gen_scalars_device(900 + j, n) for j in range(9)]
+    got = h2.msm_batch_device(cols, dp)
+    for j in (0, 3, 4, 8):
+        assert np.array_equal(aff(h2, got[j]), aff(h2, h2.msm_device(cols[j], dp))), j
