@@ -159,6 +159,25 @@ def main():
         batched = {"count": B, "ms_per_msm": tb * 1e3, "value": n * W / tb, "unit": "G1-adds/s",
                    "note": "h2hip_msm_bn254_batch_device: whole MSMs pipelined over three streams"}
         del cols
+        # the prover's size (BASELINE.json configs[4], k = 17): 16 column commits as one fused batch, against one call each
+        n17 = 1 << 17
+        cols = [h2.gen_scalars_device(0x5EED0001, n17, start=(j + 1) * n17, device=dev) for j in range(16)]
+        pts17 = d_points[:n17]
+
+        def timed(f, reps=3):
+            f()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                f()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / reps
+
+        t_fused = timed(lambda: h2.msm_batch_device(cols, pts17)) / 16
+        t_single = timed(lambda: [h2.msm_device(c_, pts17) for c_ in cols]) / 16
+        batched["k17"] = {"count": 16, "ms_per_msm": t_fused * 1e3, "ms_per_msm_one_call_each": t_single * 1e3,
+                          "note": "batches of up to 2^18 pairs run fused: one sort / accumulate / reduce over the windows of all MSMs"}
+        del cols
 
     # ---- NTT leg (BASELINE.json configs[2]: k = 22 NTT + iNTT), outside the MSM timed region ----
     ntt = None
