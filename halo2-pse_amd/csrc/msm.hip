@@ -423,12 +423,13 @@ static int msm_layout(size_t n, hipStream_t s, MsmLayout* L, uint32_t fuse = 1) 
     }
     L->n_buckets = L->Wt * p.NB;
     L->m1 = p.NB >> p.log_s1;
-    // Small inputs: one radix sort over (window, slot); large inputs: one sort per window on the slot bits only
-    // (the pairs are already window-major) -- 2 passes of 8 bits instead of 3 over all n*W pairs.
+    // Small inputs: one radix sort of all n*W pairs; large inputs: one sort per window (the pairs are already window-major).
     L->per_window_sort = n >= ((size_t)1 << 22);
-    uint32_t wbits = 0;
-    while ((1u << wbits) < L->Wt) wbits++;
-    L->end_bit = L->per_window_sort ? (int)p.c : (int)(p.c + wbits);
+    // Only the slot bits are sorted.  The pairs leave the digits kernel window-major and the radix sort is stable, so after
+    // sorting on the low c bits the entries of one (window, slot) bucket are still one contiguous run (ordered by slot, then
+    // window, then pair index) -- which is all the bounds kernel and the accumulate kernel need.  That is 2 radix passes for
+    // c <= 16 instead of the 3 a sort on (window, slot) takes.
+    L->end_bit = (int)p.c;
     L->cub_bytes = 0;
     H2_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, L->cub_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
                                                 (uint32_t*)nullptr, (int)(L->per_window_sort ? n : L->E), 0, L->end_bit, s));
