@@ -266,10 +266,12 @@ struct DigitPlan {
     uint32_t shift[8];   // bit position of digit d
 };
 
-// T laid out [w][d][v].  LPT = 64: one single-wave workgroup per T (a 64-lane tree wastes fewer issue slots than a 256-lane
-// one: a wave executes an EC add at full cost however few of its lanes are active) -- the shortest chain, for a lone MSM.
-// LPT = 16: four T's per wave, 16 lanes each: longer per-lane sums, a 4-level tree -- a third of the wave-additions, for fused
-// batches, where there are tens of thousands of T's and the kernel is throughput-bound.  grid = ceil(W * (D + 1) * 32 * LPT / 64).
+// T laid out [w][d][v]; LPT lanes of a single-wave workgroup form one T.  One wave64 already saturates its SIMD's issue
+// rate (a lone wave's EC add takes 6.5 us = 3.5 k instructions at ~4 cycles), and a wave pays full price for a tree level
+// however few of its lanes are active, so what counts is waves x chain length against the 1024 SIMDs:
+//   LPT = 32, two T's per wave: a lone MSM (2 048 T's -> one wave per SIMD, chain = sums/32 + 5 tree levels; measured 170 -> 158 us
+//   at 2^20 and 167 -> 120 us at 2^17 against one T per wave);
+//   LPT = 16, four T's per wave: fused batches, tens of thousands of T's, throughput-bound (a third of the wave-additions of LPT = 64).
 template <int LPT>
 __global__ void __launch_bounds__(64) msm_reduce2_kernel(const XYZZu* __restrict__ acc_in, const XYZZu* __restrict__ run_in, uint32_t m1,
                                                          DigitPlan dp, uint32_t n_T, XYZZu* __restrict__ T) {
@@ -558,7 +560,7 @@ static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_ws, hipSt
         if (L.fuse > 1)
             hipLaunchKernelGGL(msm_reduce2_kernel<16>, dim3((n_T + 3) / 4), dim3(64), 0, s, accs, runs, L.m1, L.dplan, n_T, Tsum);
         else
-            hipLaunchKernelGGL(msm_reduce2_kernel<64>, dim3(n_T), dim3(64), 0, s, accs, runs, L.m1, L.dplan, n_T, Tsum);
+            hipLaunchKernelGGL(msm_reduce2_kernel<32>, dim3((n_T + 1) / 2), dim3(64), 0, s, accs, runs, L.m1, L.dplan, n_T, Tsum);
     }
     H2_CHECK(hipGetLastError());
     hipLaunchKernelGGL(msm_reduce3_kernel, dim3(L.Wt), dim3(256), 0, s, Tsum, L.dplan, p.log_s1, wsum);
