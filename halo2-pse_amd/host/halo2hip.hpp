@@ -267,6 +267,22 @@ class ParamsKZG {
         return arithmetic::best_multiexp(poly.values, g_lagrange.data(), poly.len());                           // :291
     }
 
+    // The column loop of create_proof (plonk/prover.rs:361-365: `params.commit_lagrange(poly, blind)` over all advice
+    // polynomials) as one engine call; equal to calling commit_lagrange on each.
+    std::vector<G1> commit_lagrange_many(const std::vector<const Polynomial<LagrangeCoeff>*>& polys) const {
+        std::vector<G1> out(polys.size());
+        if (polys.empty()) return out;
+        const size_t size = polys[0]->len();
+        if (g_lagrange.size() < size) throw std::logic_error("assertion failed: bases.len() >= size");            // :290
+        std::vector<const uint64_t*> ptrs;
+        for (auto* p : polys) {
+            if (p->len() != size) throw std::logic_error("commit_lagrange_many: polynomials of different lengths");
+            ptrs.push_back(p->values[0].l);
+        }
+        engine_check(h2hip_msm_bn254_batch(ptrs.data(), g_lagrange[0].x, size, ptrs.size(), out[0].x), "h2hip_msm_bn254_batch");
+        return out;
+    }
+
     // commit (poly/kzg/commitment.rs:327-334)
     G1 commit(const Polynomial<Coeff>& poly, const Blind&) const {
         if (g.size() < poly.len()) throw std::logic_error("assertion failed: bases.len() >= size");           // :332

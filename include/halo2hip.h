@@ -74,8 +74,9 @@ int h2hip_msm_bn254_device(const void* d_scalars, const void* d_bases_xy, size_t
 /* `count` independent MSMs of n pairs each over the SAME bases: out_xyz[12*j..] = sum_i scalars[j][i] * bases[i].
  * This is what create_proof does when it commits its columns back to back (plonk/prover.rs:361-365:
  * `params.commit_lagrange(poly, blind)` for every advice polynomial; lookup/prover.rs:127-132, :291;
- * vanishing/prover.rs:104).  Results equal `count` separate h2hip_msm_bn254 calls; the engine pipelines whole
- * MSMs over three streams (sort of j+1 and reduction of j-1 under the accumulation of j). */
+ * vanishing/prover.rs:104).  Results equal `count` separate h2hip_msm_bn254 calls.  Up to 2^18 pairs the MSMs of a batch
+ * run fused (one sort / accumulate / reduce over the windows of all of them); larger ones are pipelined whole over three
+ * streams (sort of j+1 and reduction of j-1 under the accumulation of j). */
 int h2hip_msm_bn254_batch(const uint64_t* const* scalars, const uint64_t* bases_xy, size_t n, size_t count, uint64_t* out_xyz);
 int h2hip_msm_bn254_batch_device(const void* const* d_scalars, const void* d_bases_xy, size_t n, size_t count, uint64_t* out_xyz, void* stream);
 

@@ -60,6 +60,18 @@ static void test_commit_lagrange(const std::string& dir) {
         CHECK(small.commit(d4.lagrange_to_coeff(a4), alpha) == small.commit_lagrange(a4, alpha));
         CHECK(panics([&] { small.downsize(5); }));
     }
+    // the batched column commit equals one commit_lagrange per column
+    {
+        std::vector<Polynomial<LagrangeCoeff>> cols(5, domain.empty_lagrange());
+        std::vector<const Polynomial<LagrangeCoeff>*> ptrs;
+        for (size_t c = 0; c < cols.size(); c++) {
+            for (size_t i = 0; i < cols[c].len(); i++) cols[c][i] = Fr::from(1000 * c + i * i + 7);
+            ptrs.push_back(&cols[c]);
+        }
+        std::vector<G1> many = params.commit_lagrange_many(ptrs);
+        CHECK(many.size() == cols.size());
+        for (size_t c = 0; c < cols.size(); c++) CHECK(many[c] == params.commit_lagrange(cols[c], alpha));
+    }
     // the blind is ignored by KZG commit (poly/kzg/commitment.rs:284,327)
     CHECK(params.commit(b, Blind{Fr::zero()}).to_affine() == params.commit(b, alpha).to_affine());
 }
