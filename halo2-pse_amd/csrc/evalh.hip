@@ -533,29 +533,6 @@ static size_t prog_bytes(const h2hip_graph& g, const Program& P) {
     return 3 * 256 + g.n_constants * sizeof(Fu) + g.n_rotations * 4 + P.ops.size() * sizeof(DevOp);
 }
 
-static int prog_upload(Arena& ar, const h2hip_graph& g, const Program& P, ProgDev* out, hipStream_t s) {
-    Fu* dc = (Fu*)ar.take(g.n_constants * sizeof(Fu));
-    int32_t* dr = (int32_t*)ar.take(g.n_rotations * 4);
-    DevOp* dq = (DevOp*)ar.take(P.ops.size() * sizeof(DevOp));
-    if (!dc || !dr || !dq) {
-        set_error("evaluate_h: arena overflow");
-        return 1;
-    }
-    if (g.n_constants) {
-        std::vector<Fu> hc(g.n_constants);
-        for (uint32_t i = 0; i < g.n_constants; i++) hc[i] = to_i(load_fe(g.constants + 4 * (size_t)i));
-        H2_CHECK(hipMemcpyAsync(dc, hc.data(), hc.size() * sizeof(Fu), hipMemcpyHostToDevice, s));  // pageable: staged before return
-    }
-    if (g.n_rotations) H2_CHECK(hipMemcpyAsync(dr, g.rotations, g.n_rotations * 4, hipMemcpyHostToDevice, s));
-    if (!P.ops.empty()) H2_CHECK(hipMemcpyAsync(dq, P.ops.data(), P.ops.size() * sizeof(DevOp), hipMemcpyHostToDevice, s));
-    out->constants = dc;
-    out->rotations = dr;
-    out->ops = dq;
-    out->n_ops = (uint32_t)P.ops.size();
-    out->result = P.result;
-    return 0;
-}
-
 // Where the slots of a program live: per-lane scratch in three sizes, or (past 256) a global workspace of
 // n_slots x lanes elements with the rows taken grid-stride by `lanes` threads.
 struct SlotPlan {
@@ -643,19 +620,48 @@ int evaluate_h_validate(const h2hip_evalh_desc* d, const void* values) {
     return 0;
 }
 
+// Everything small the kernels read (programs, constants, rotations, column-pointer tables, challenges, the power table)
+// is laid out in one host image of a metadata region at the head of the arena and uploaded with ONE copy before any kernel
+// is queued.  A copy from pageable memory is synchronous in HIP and ordered after the stream's earlier work, so a copy
+// between two kernels would make the host wait for the first and leave the GPU idle until the second is launched.
+struct MetaBlob {
+    std::vector<char> host;
+    char* dev_base = nullptr;
+    size_t cap = 0;
+    bool overflow = false;
+    template <class T>
+    T* put(const T* src, size_t count) {
+        size_t off = (host.size() + 255) / 256 * 256;
+        const size_t bytes = count * sizeof(T);
+        if (off + bytes > cap) {
+            overflow = true;
+            return (T*)dev_base;
+        }
+        host.resize(off + bytes);
+        if (bytes) memcpy(host.data() + off, src, bytes);
+        return (T*)(dev_base + off);
+    }
+};
+
+static void prog_put(MetaBlob& mb, const h2hip_graph& g, const Program& P, ProgDev* out) {
+    std::vector<Fu> hc(g.n_constants);
+    for (uint32_t i = 0; i < g.n_constants; i++) hc[i] = to_i(load_fe(g.constants + 4 * (size_t)i));
+    out->constants = mb.put(hc.data(), hc.size());
+    out->rotations = mb.put(g.rotations, g.n_rotations);
+    out->ops = mb.put(P.ops.data(), P.ops.size());
+    out->n_ops = (uint32_t)P.ops.size();
+    out->result = P.result;
+}
+
 // dev = false: every column pointer in `d` and `values` are host memory (the reference's Vec<F>s); values is updated in place
 //              and the call returns when it is.
-// dev = true:  the columns and `values` are device memory (extended cosets are used where they lie, coefficient-form
-//              polynomials are copied device-to-device before they are extended); the graphs, challenges and scalars stay
-//              host pointers; the kernels are queued on `s` and the call returns without waiting for them.
+// dev = true:  the columns and `values` are device memory (extended cosets are used where they lie, the first NTT pass reads
+//              coefficient-form polynomials where they lie); the graphs, challenges and scalars stay host pointers; the
+//              kernels are queued on `s` and the call returns without waiting for them.
 int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool dev, hipStream_t s) {
     const uint32_t k = d->k, ek = d->extended_k;
     const size_t n = (size_t)1 << k, size = (size_t)1 << ek;
     const size_t col_bytes = size * sizeof(Fe);
-    // ---- device arena
-    const size_t n_cols = dev ? (size_t)d->n_advice + d->n_instance + 3
-                              : (size_t)d->n_fixed + d->n_advice + d->n_instance + 3 /* l0, l_last, l_active */ + d->n_perm_sets + d->n_perm_columns +
-                                    3 /* lookup cosets, reused */ + 1 /* values */;
     // programs first: their slot counts size the workspaces
     const Program gates_prog = compile_graph(d->custom_gates);
     std::vector<Program> lookup_progs(d->n_lookups);
@@ -669,91 +675,89 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         if ((rc = slot_plan(lookup_progs[i].n_slots, size, &lookup_plans[i]))) return rc;
         if (lookup_plans[i].ws_bytes > slots_ws) slots_ws = lookup_plans[i].ws_bytes;
     }
-    size_t need = n_cols * (col_bytes + 256) + 64 * 1024 + prog_bytes(d->custom_gates, gates_prog) + (size_t)d->n_challenges * sizeof(Fu) +
-                  8 * ((size_t)d->n_fixed + d->n_advice + d->n_instance + d->n_perm_sets + 2 * (size_t)d->n_perm_columns + 16) + 4096;
-    for (uint32_t i = 0; i < d->n_lookups; i++) need += prog_bytes(d->lookup_graphs[i], lookup_progs[i]);
-    if ((rc = c->evalh_ws.ensure(need))) return rc;
+    // ---- device arena: [metadata | columns the engine owns]
+    const size_t n_cols = dev ? (size_t)d->n_advice + d->n_instance + 3
+                              : (size_t)d->n_fixed + d->n_advice + d->n_instance + 3 /* l0, l_last, l_active */ + d->n_perm_sets + d->n_perm_columns +
+                                    3 /* lookup cosets, reused */ + 1 /* values */;
+    size_t meta_cap = 64 * 1024 + prog_bytes(d->custom_gates, gates_prog) + ((size_t)d->n_challenges + 28) * sizeof(Fu) +
+                      (8 + 256) * ((size_t)d->n_fixed + d->n_advice + d->n_instance + d->n_perm_sets + 2 * (size_t)d->n_perm_columns + 16);
+    for (uint32_t i = 0; i < d->n_lookups; i++) meta_cap += prog_bytes(d->lookup_graphs[i], lookup_progs[i]);
+    meta_cap = (meta_cap + 255) / 256 * 256;
+    if ((rc = c->evalh_ws.ensure(meta_cap + n_cols * (col_bytes + 256) + 4096))) return rc;
     if (slots_ws && (rc = c->evalh_slots.ensure(slots_ws))) return rc;
     Fu* const gws = (Fu*)c->evalh_slots.p;
     if ((rc = c->ws_acquire(s))) return rc;
-    const hipMemcpyKind in_kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     Arena ar;
     ar.base = (char*)c->evalh_ws.p;
     ar.cap = c->evalh_ws.cap;
-    auto col_upload = [&](const uint64_t* h, size_t elems, Fe** out) -> int {
-        if (dev && elems == size && h) {  // an extended coset already in HBM: used where it lies
-            *out = (Fe*)h;
-            return 0;
+    MetaBlob mb;
+    mb.dev_base = (char*)ar.take(meta_cap);
+    mb.cap = meta_cap;
+    if (!mb.dev_base) {
+        set_error("evaluate_h: arena overflow");
+        return 1;
+    }
+    // where every column will live: an extended coset already in HBM is used in place, anything else gets arena space
+    struct Upload { Fe* dst; const uint64_t* src; size_t elems; };
+    std::vector<Upload> uploads;  // host -> device column copies, issued after the metadata
+    bool bad = false;
+    auto place = [&](const uint64_t* h, size_t elems) -> Fe* {
+        if (!h) {
+            bad = true;
+            return nullptr;
         }
+        if (dev && elems == size) return (Fe*)h;
         Fe* p = (Fe*)ar.take(col_bytes);
-        if (!p || !h) {
-            set_error("evaluate_h: null column or arena overflow");
-            return 1;
-        }
-        H2_CHECK(hipMemcpyAsync(p, h, elems * sizeof(Fe), in_kind, s));
-        *out = p;
-        return 0;
+        if (!p) bad = true;
+        else if (!dev) uploads.push_back({p, h, elems});
+        return p;
     };
-    const Fe ext_omega = load_fe(d->extended_omega);
-    NttScale sc;
-    {   // distribute_powers_zeta(into_coset) + zero-pad + NTT, as h2hip_coeff_to_extended does
-        sc.in_scale = true;
-        sc.in3[0] = fe_one<FrP>();
-        sc.in3[1] = load_fe(d->g_coset);
-        sc.in3[2] = load_fe(d->g_coset_inv);
-        sc.in_len = n;
-    }
-    // advice and instance polynomials -> extended cosets (:306-323), all in one batched transform: uploads (or, device
-    // resident, nothing: the first pass reads the coefficients where they lie) first, then one launch per NTT pass
     std::vector<const Fe*> fixed(d->n_fixed), advice(d->n_advice), instance(d->n_instance);
-    Fe* tmp;
-    for (uint32_t i = 0; i < d->n_fixed; i++) { if ((rc = col_upload(d->fixed_cosets[i], size, &tmp))) return rc; fixed[i] = tmp; }
-    {
-        const size_t n_polys = (size_t)d->n_advice + d->n_instance;
-        std::vector<Fe*> datas(n_polys);
-        std::vector<const Fe*> srcs(n_polys, nullptr);
-        for (size_t i = 0; i < n_polys; i++) {
-            const uint64_t* h = i < d->n_advice ? d->advice_polys[i] : d->instance_polys[i - d->n_advice];
-            Fe* p = (Fe*)ar.take(col_bytes);
-            if (!p || !h) {
-                set_error("evaluate_h: null column or arena overflow");
-                return 1;
-            }
-            if (dev) srcs[i] = (const Fe*)h;
-            else H2_CHECK(hipMemcpyAsync(p, h, n * sizeof(Fe), hipMemcpyHostToDevice, s));
-            datas[i] = p;
-            (i < d->n_advice ? advice[i] : instance[i - d->n_advice]) = p;
-        }
-        if ((rc = ntt_device_batch(c, datas.data(), srcs.data(), n_polys, ext_omega, ek, &sc, s))) return rc;
+    for (uint32_t i = 0; i < d->n_fixed; i++) fixed[i] = place(d->fixed_cosets[i], size);
+    const size_t n_polys = (size_t)d->n_advice + d->n_instance;
+    std::vector<Fe*> poly_dst(n_polys);
+    std::vector<const Fe*> poly_src(n_polys, nullptr);
+    for (size_t i = 0; i < n_polys; i++) {
+        const uint64_t* h = i < d->n_advice ? d->advice_polys[i] : d->instance_polys[i - d->n_advice];
+        Fe* p = (Fe*)ar.take(col_bytes);
+        if (!p || !h) bad = true;
+        if (dev) poly_src[i] = (const Fe*)h;  // the first NTT pass reads the coefficients where they lie
+        else uploads.push_back({p, h, n});
+        poly_dst[i] = p;
+        (i < d->n_advice ? advice[i] : instance[i - d->n_advice]) = p;
     }
-    Fe *l0, *l_last, *l_active, *d_values;
-    if ((rc = col_upload(d->l0, size, &l0)) || (rc = col_upload(d->l_last, size, &l_last)) || (rc = col_upload(d->l_active_row, size, &l_active)) ||
-        (rc = col_upload(values, size, &d_values)))
-        return rc;
-    auto ptrs_upload = [&](const std::vector<const Fe*>& v, const Fe* const** out) -> int {
-        const Fe** p = (const Fe**)ar.take((v.size() + 1) * sizeof(Fe*));
-        if (!p) {
-            set_error("evaluate_h: arena overflow");
-            return 1;
+    Fe* const l0 = place(d->l0, size);
+    Fe* const l_last = place(d->l_last, size);
+    Fe* const l_active = place(d->l_active_row, size);
+    Fe* const d_values = place(values, size);
+    std::vector<const Fe*> z(d->n_perm_sets), pcols(d->n_perm_sets ? d->n_perm_columns : 0), pcosets(d->n_perm_sets ? d->n_perm_columns : 0);
+    if (d->n_perm_sets) {
+        for (uint32_t i = 0; i < d->n_perm_sets; i++) z[i] = place(d->perm_product_cosets[i], size);
+        for (uint32_t j = 0; j < d->n_perm_columns; j++) {
+            pcosets[j] = place(d->perm_cosets[j], size);
+            const uint32_t kind = d->perm_column_kind[j], idx = d->perm_column_index[j];
+            pcols[j] = kind == H2HIP_ANY_ADVICE ? advice[idx] : kind == H2HIP_ANY_FIXED ? fixed[idx] : instance[idx];  // :404-408
         }
-        if (!v.empty()) H2_CHECK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(Fe*), hipMemcpyHostToDevice, s));
-        *out = p;
-        return 0;
-    };
+    }
+    Fe* lbuf[3] = {nullptr, nullptr, nullptr};
+    if (d->n_lookups)
+        for (int t = 0; t < 3; t++)
+            if (!(lbuf[t] = (Fe*)ar.take(col_bytes))) bad = true;
+    for (uint32_t i = 0; i < d->n_lookups; i++)
+        if (!d->lookup_product_polys[i] || !d->lookup_permuted_input_polys[i] || !d->lookup_permuted_table_polys[i]) bad = true;
+    if (bad) {
+        set_error("evaluate_h: null column or arena overflow");
+        return 1;
+    }
+    // ---- metadata image
     ColsDev cols;
-    if ((rc = ptrs_upload(fixed, &cols.fixed)) || (rc = ptrs_upload(advice, &cols.advice)) || (rc = ptrs_upload(instance, &cols.instance))) return rc;
+    cols.fixed = mb.put(fixed.data(), fixed.size());
+    cols.advice = mb.put(advice.data(), advice.size());
+    cols.instance = mb.put(instance.data(), instance.size());
     {
-        Fu* dch = (Fu*)ar.take((d->n_challenges + 1) * sizeof(Fu));
-        if (!dch) {
-            set_error("evaluate_h: arena overflow");
-            return 1;
-        }
-        if (d->n_challenges) {
-            std::vector<Fu> hch(d->n_challenges);
-            for (uint32_t i = 0; i < d->n_challenges; i++) hch[i] = to_i(load_fe(d->challenges + 4 * (size_t)i));
-            H2_CHECK(hipMemcpyAsync(dch, hch.data(), hch.size() * sizeof(Fu), hipMemcpyHostToDevice, s));
-        }
-        cols.challenges = dch;
+        std::vector<Fu> hch(d->n_challenges);
+        for (uint32_t i = 0; i < d->n_challenges; i++) hch[i] = to_i(load_fe(d->challenges + 4 * (size_t)i));
+        cols.challenges = mb.put(hch.data(), hch.size());
     }
     cols.beta = to_i(load_fe(d->beta));
     cols.gamma = to_i(load_fe(d->gamma));
@@ -761,11 +765,52 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
     cols.y = to_i(load_fe(d->y));
     cols.log_size = ek;
     cols.rot_scale = 1 << (ek - k);
+    const Fe ext_omega = load_fe(d->extended_omega);
+    ProgDev gd;
+    prog_put(mb, d->custom_gates, gates_prog, &gd);
+    std::vector<ProgDev> lgs(d->n_lookups);
+    for (uint32_t i = 0; i < d->n_lookups; i++) prog_put(mb, d->lookup_graphs[i], lookup_progs[i], &lgs[i]);
+    PermDev pd;
+    memset(&pd, 0, sizeof(pd));
+    if (d->n_perm_sets) {
+        pd.z = mb.put(z.data(), z.size());
+        pd.cols = mb.put(pcols.data(), pcols.size());
+        pd.cosets = mb.put(pcosets.data(), pcosets.size());
+        Fe pw = ext_omega;
+        Fu pwi[28];
+        for (int j = 0; j < 28; j++) {
+            pwi[j] = to_i(pw);
+            pw = fe_sqr<FrP>(pw);
+        }
+        pd.omega_pow2 = mb.put(pwi, 28);
+        pd.l0 = l0;
+        pd.l_last = l_last;
+        pd.l_active = l_active;
+        pd.delta = to_i(load_fe(d->delta));
+        pd.delta_start = to_i(fe_mul<FrP>(load_fe(d->beta), load_fe(d->zeta)));
+        pd.n_sets = d->n_perm_sets;
+        pd.n_cols = d->n_perm_columns;
+        pd.chunk_len = d->chunk_len;
+        pd.last_rotation = d->last_rotation;
+    }
+    if (mb.overflow) {
+        set_error("evaluate_h: metadata region overflow");
+        return 1;
+    }
+    if (!mb.host.empty()) H2_CHECK(hipMemcpyAsync(mb.dev_base, mb.host.data(), mb.host.size(), hipMemcpyHostToDevice, s));
+    // ---- columns: host -> device copies (host-pointer form), then advice / instance polynomials -> extended cosets
+    //      (:306-323) in one batched transform: distribute_powers_zeta(into_coset) + zero-pad + NTT, as h2hip_coeff_to_extended does
+    for (const Upload& u : uploads) H2_CHECK(hipMemcpyAsync(u.dst, u.src, u.elems * sizeof(Fe), hipMemcpyHostToDevice, s));
+    NttScale sc;
+    sc.in_scale = true;
+    sc.in3[0] = fe_one<FrP>();
+    sc.in3[1] = load_fe(d->g_coset);
+    sc.in3[2] = load_fe(d->g_coset_inv);
+    sc.in_len = n;
+    if ((rc = ntt_device_batch(c, poly_dst.data(), poly_src.data(), n_polys, ext_omega, ek, &sc, s))) return rc;
     const dim3 grid((uint32_t)((size + 255) / 256)), block(256);
 
     // ---- custom gates (:334-360)
-    ProgDev gd;
-    if ((rc = prog_upload(ar, d->custom_gates, gates_prog, &gd, s))) return rc;
     {
         const dim3 g(gates_plan.lanes / 256);
         switch (gates_plan.tier) {
@@ -781,79 +826,32 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
 
     // ---- permutations (:362-441)
     if (d->n_perm_sets) {
-        std::vector<const Fe*> z(d->n_perm_sets), pcols(d->n_perm_columns), pcosets(d->n_perm_columns);
-        for (uint32_t i = 0; i < d->n_perm_sets; i++) { if ((rc = col_upload(d->perm_product_cosets[i], size, &tmp))) return rc; z[i] = tmp; }
-        for (uint32_t j = 0; j < d->n_perm_columns; j++) {
-            if ((rc = col_upload(d->perm_cosets[j], size, &tmp))) return rc;
-            pcosets[j] = tmp;
-            uint32_t kind = d->perm_column_kind[j], idx = d->perm_column_index[j];
-            pcols[j] = kind == H2HIP_ANY_ADVICE ? advice[idx] : kind == H2HIP_ANY_FIXED ? fixed[idx] : instance[idx];  // :404-408
-        }
-        PermDev pd;
-        if ((rc = ptrs_upload(z, &pd.z)) || (rc = ptrs_upload(pcols, &pd.cols)) || (rc = ptrs_upload(pcosets, &pd.cosets))) return rc;
-        pd.l0 = l0;
-        pd.l_last = l_last;
-        pd.l_active = l_active;
-        {
-            Fe pw = ext_omega;
-            Fu pwi[28];
-            for (int j = 0; j < 28; j++) {
-                pwi[j] = to_i(pw);
-                pw = fe_sqr<FrP>(pw);
-            }
-            Fu* d_pw = (Fu*)ar.take(sizeof(pwi));
-            if (!d_pw) {
-                set_error("evaluate_h: arena overflow");
-                return 1;
-            }
-            H2_CHECK(hipMemcpyAsync(d_pw, pwi, sizeof(pwi), hipMemcpyHostToDevice, s));
-            pd.omega_pow2 = d_pw;
-        }
-        pd.delta = to_i(load_fe(d->delta));
-        pd.delta_start = to_i(fe_mul<FrP>(load_fe(d->beta), load_fe(d->zeta)));
-        pd.n_sets = d->n_perm_sets;
-        pd.n_cols = d->n_perm_columns;
-        pd.chunk_len = d->chunk_len;
-        pd.last_rotation = d->last_rotation;
         hipLaunchKernelGGL(evalh_perm_kernel, grid, block, 0, s, pd, cols, d_values);
         H2_CHECK(hipGetLastError());
     }
 
     // ---- lookups (:443-518): the three cosets of a lookup are formed, used and their buffers reused
-    if (d->n_lookups) {
-        Fe* buf[3];
-        for (int t = 0; t < 3; t++)
-            if (!(buf[t] = (Fe*)ar.take(col_bytes))) {
-                set_error("evaluate_h: arena overflow");
-                return 1;
-            }
-        for (uint32_t i = 0; i < d->n_lookups; i++) {
-            const uint64_t* polys[3] = {d->lookup_product_polys[i], d->lookup_permuted_input_polys[i], d->lookup_permuted_table_polys[i]};
-            const Fe* lsrc[3] = {nullptr, nullptr, nullptr};
-            for (int t = 0; t < 3; t++) {
-                if (!polys[t]) {
-                    set_error("evaluate_h: null lookup polynomial");
-                    return 1;
-                }
-                if (dev) lsrc[t] = (const Fe*)polys[t];
-                else H2_CHECK(hipMemcpyAsync(buf[t], polys[t], n * sizeof(Fe), hipMemcpyHostToDevice, s));
-            }
-            if ((rc = ntt_device_batch(c, buf, lsrc, 3, ext_omega, ek, &sc, s))) return rc;
-            ProgDev lg;
-            if ((rc = prog_upload(ar, d->lookup_graphs[i], lookup_progs[i], &lg, s))) return rc;
-            LookupDev ld = {buf[0], buf[1], buf[2], l0, l_last, l_active};
-            const SlotPlan& lp = lookup_plans[i];
-            const dim3 g(lp.lanes / 256);
-            switch (lp.tier) {
-                case 4: hipLaunchKernelGGL(evalh_lookup_kernel<4>, g, block, 4 * 9 * 256 * 4, s, lg, ld, cols, d_values, gws, lp.lanes); break;
-                case 8: hipLaunchKernelGGL(evalh_lookup_kernel<8>, g, block, 8 * 9 * 256 * 4, s, lg, ld, cols, d_values, gws, lp.lanes); break;
-                case 16: hipLaunchKernelGGL(evalh_lookup_kernel<16>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
-                case 64: hipLaunchKernelGGL(evalh_lookup_kernel<64>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
-                case 256: hipLaunchKernelGGL(evalh_lookup_kernel<256>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
-                default: hipLaunchKernelGGL(evalh_lookup_kernel<0>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes);
-            }
-            H2_CHECK(hipGetLastError());
+    for (uint32_t i = 0; i < d->n_lookups; i++) {
+        const uint64_t* polys[3] = {d->lookup_product_polys[i], d->lookup_permuted_input_polys[i], d->lookup_permuted_table_polys[i]};
+        const Fe* lsrc[3] = {nullptr, nullptr, nullptr};
+        for (int t = 0; t < 3; t++) {
+            if (dev) lsrc[t] = (const Fe*)polys[t];
+            else H2_CHECK(hipMemcpyAsync(lbuf[t], polys[t], n * sizeof(Fe), hipMemcpyHostToDevice, s));
         }
+        if ((rc = ntt_device_batch(c, lbuf, lsrc, 3, ext_omega, ek, &sc, s))) return rc;
+        const ProgDev& lg = lgs[i];
+        LookupDev ld = {lbuf[0], lbuf[1], lbuf[2], l0, l_last, l_active};
+        const SlotPlan& lp = lookup_plans[i];
+        const dim3 g(lp.lanes / 256);
+        switch (lp.tier) {
+            case 4: hipLaunchKernelGGL(evalh_lookup_kernel<4>, g, block, 4 * 9 * 256 * 4, s, lg, ld, cols, d_values, gws, lp.lanes); break;
+            case 8: hipLaunchKernelGGL(evalh_lookup_kernel<8>, g, block, 8 * 9 * 256 * 4, s, lg, ld, cols, d_values, gws, lp.lanes); break;
+            case 16: hipLaunchKernelGGL(evalh_lookup_kernel<16>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
+            case 64: hipLaunchKernelGGL(evalh_lookup_kernel<64>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
+            case 256: hipLaunchKernelGGL(evalh_lookup_kernel<256>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
+            default: hipLaunchKernelGGL(evalh_lookup_kernel<0>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes);
+        }
+        H2_CHECK(hipGetLastError());
     }
     if ((rc = c->ws_release(s))) return rc;
     if (dev) return 0;
