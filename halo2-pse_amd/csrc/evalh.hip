@@ -12,6 +12,7 @@
 // VALU-bound inner loop of the MSM, and canonical values make bit-exactness with the reference immediate.
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../include/halo2hip.h"
@@ -107,30 +108,38 @@ __device__ __forceinline__ Fu mul_i(const Fu& a, const Fu& b) { return fu_mul<UF
 __device__ __forceinline__ Fe out_e(const Fu& a) { return fu_mul_canon<UF>(a, fu_one_e<UF>()); }  // |a| < 16 r -> canonical E
 
 // slot storage: MAXI > 0 -> per-lane scratch; MAXI == 0 -> a global workspace laid out [slot][lane] (coalesced per slot)
+extern __shared__ int32_t evalh_lds[];
+#define EVALH_LDS_HOT 4  // slots of a scratch-tier program that live in LDS
+__device__ __forceinline__ Fu lds_slot_get(uint32_t i) {
+    Fu r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.l[k] = evalh_lds[(i * 9 + k) * 256 + threadIdx.x];
+    return r;
+}
+__device__ __forceinline__ void lds_slot_set(uint32_t i, const Fu& x) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) evalh_lds[(i * 9 + k) * 256 + threadIdx.x] = x.l[k];
+}
+// 16 / 64 / 256 slots: the first EVALH_LDS_HOT in LDS, the rest in per-lane scratch; compile_graph numbers the slots by
+// how often the program touches them, busiest first.
 template <int MAXI>
 struct Slots {
-    Fu v[MAXI];
+    Fu v[MAXI - EVALH_LDS_HOT];
     __device__ __forceinline__ Slots(Fu*, size_t) {}
-    __device__ __forceinline__ Fu get(uint32_t i) const { return v[i]; }
-    __device__ __forceinline__ void set(uint32_t i, const Fu& x) { v[i] = x; }
+    __device__ __forceinline__ Fu get(uint32_t i) const { return i < EVALH_LDS_HOT ? lds_slot_get(i) : v[i - EVALH_LDS_HOT]; }
+    __device__ __forceinline__ void set(uint32_t i, const Fu& x) {
+        if (i < EVALH_LDS_HOT) lds_slot_set(i, x);
+        else v[i - EVALH_LDS_HOT] = x;
+    }
 };
 // few slots (the common case: a gate polynomial is folded as soon as it exists): LDS, laid out [slot][limb][thread] so
 // that a wave's access is one conflict-free row.  (Registers would be better still, but the slot index is only known at
 // run time and LLVM turns any select chain over would-be register slots back into an indexed scratch access.)
-extern __shared__ int32_t evalh_lds[];
 template <int N>
 struct LdsSlots {
     __device__ __forceinline__ LdsSlots(Fu*, size_t) {}
-    __device__ __forceinline__ Fu get(uint32_t i) const {
-        Fu r;
-#pragma unroll
-        for (int k = 0; k < 9; k++) r.l[k] = evalh_lds[(i * 9 + k) * 256 + threadIdx.x];
-        return r;
-    }
-    __device__ __forceinline__ void set(uint32_t i, const Fu& x) {
-#pragma unroll
-        for (int k = 0; k < 9; k++) evalh_lds[(i * 9 + k) * 256 + threadIdx.x] = x.l[k];
-    }
+    __device__ __forceinline__ Fu get(uint32_t i) const { return lds_slot_get(i); }
+    __device__ __forceinline__ void set(uint32_t i, const Fu& x) { lds_slot_set(i, x); }
 };
 template <>
 struct Slots<4> : LdsSlots<4> {
@@ -515,6 +524,26 @@ static Program compile_graph(const h2hip_graph& g) {
         result.a = slot[result.a];
         if (slot_mag[result.a] > EVALH_MAG_RESULT) P.ops.push_back({OP_MOV | OP_REDUCE_FLAG, result.a, result, none});
     }
+    // 5. renumber the slots by how often the program touches them, busiest first: the kernels keep the lowest-numbered
+    //    slots in LDS and the rest in scratch
+    {
+        std::vector<uint64_t> touches(P.n_slots, 0);
+        for (const DevOp& o : P.ops) {
+            touches[o.dst] += (o.op & 0xff) == OP_FMA ? 2 : 1;
+            if (o.x.kind == H2HIP_VS_INTERMEDIATE) touches[o.x.a]++;
+            if (o.y.kind == H2HIP_VS_INTERMEDIATE) touches[o.y.a]++;
+        }
+        std::vector<uint32_t> order(P.n_slots), renum(P.n_slots);
+        for (uint32_t i = 0; i < P.n_slots; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a_, uint32_t b_) { return touches[a_] > touches[b_]; });
+        for (uint32_t i = 0; i < P.n_slots; i++) renum[order[i]] = i;
+        for (DevOp& o : P.ops) {
+            o.dst = renum[o.dst];
+            if (o.x.kind == H2HIP_VS_INTERMEDIATE) o.x.a = renum[o.x.a];
+            if (o.y.kind == H2HIP_VS_INTERMEDIATE) o.y.a = renum[o.y.a];
+        }
+        if (result.kind == H2HIP_VS_INTERMEDIATE) result.a = renum[result.a];
+    }
     P.result = result;
     return P;
 }
@@ -816,9 +845,9 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         switch (gates_plan.tier) {
             case 4: hipLaunchKernelGGL(evalh_gates_kernel<4>, g, block, 4 * 9 * 256 * 4, s, gd, cols, d_values, gws, gates_plan.lanes); break;
             case 8: hipLaunchKernelGGL(evalh_gates_kernel<8>, g, block, 8 * 9 * 256 * 4, s, gd, cols, d_values, gws, gates_plan.lanes); break;
-            case 16: hipLaunchKernelGGL(evalh_gates_kernel<16>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes); break;
-            case 64: hipLaunchKernelGGL(evalh_gates_kernel<64>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes); break;
-            case 256: hipLaunchKernelGGL(evalh_gates_kernel<256>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes); break;
+            case 16: hipLaunchKernelGGL(evalh_gates_kernel<16>, g, block, EVALH_LDS_HOT * 9 * 256 * 4, s, gd, cols, d_values, gws, gates_plan.lanes); break;
+            case 64: hipLaunchKernelGGL(evalh_gates_kernel<64>, g, block, EVALH_LDS_HOT * 9 * 256 * 4, s, gd, cols, d_values, gws, gates_plan.lanes); break;
+            case 256: hipLaunchKernelGGL(evalh_gates_kernel<256>, g, block, EVALH_LDS_HOT * 9 * 256 * 4, s, gd, cols, d_values, gws, gates_plan.lanes); break;
             default: hipLaunchKernelGGL(evalh_gates_kernel<0>, g, block, 0, s, gd, cols, d_values, gws, gates_plan.lanes);
         }
     }
@@ -846,9 +875,9 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         switch (lp.tier) {
             case 4: hipLaunchKernelGGL(evalh_lookup_kernel<4>, g, block, 4 * 9 * 256 * 4, s, lg, ld, cols, d_values, gws, lp.lanes); break;
             case 8: hipLaunchKernelGGL(evalh_lookup_kernel<8>, g, block, 8 * 9 * 256 * 4, s, lg, ld, cols, d_values, gws, lp.lanes); break;
-            case 16: hipLaunchKernelGGL(evalh_lookup_kernel<16>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
-            case 64: hipLaunchKernelGGL(evalh_lookup_kernel<64>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
-            case 256: hipLaunchKernelGGL(evalh_lookup_kernel<256>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes); break;
+            case 16: hipLaunchKernelGGL(evalh_lookup_kernel<16>, g, block, EVALH_LDS_HOT * 9 * 256 * 4, s, lg, ld, cols, d_values, gws, lp.lanes); break;
+            case 64: hipLaunchKernelGGL(evalh_lookup_kernel<64>, g, block, EVALH_LDS_HOT * 9 * 256 * 4, s, lg, ld, cols, d_values, gws, lp.lanes); break;
+            case 256: hipLaunchKernelGGL(evalh_lookup_kernel<256>, g, block, EVALH_LDS_HOT * 9 * 256 * 4, s, lg, ld, cols, d_values, gws, lp.lanes); break;
             default: hipLaunchKernelGGL(evalh_lookup_kernel<0>, g, block, 0, s, lg, ld, cols, d_values, gws, lp.lanes);
         }
         H2_CHECK(hipGetLastError());
