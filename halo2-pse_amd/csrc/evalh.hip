@@ -109,7 +109,8 @@ __device__ __forceinline__ Fe out_e(const Fu& a) { return fu_mul_canon<UF>(a, fu
 
 // slot storage: MAXI > 0 -> per-lane scratch; MAXI == 0 -> a global workspace laid out [slot][lane] (coalesced per slot)
 extern __shared__ int32_t evalh_lds[];
-#define EVALH_LDS_HOT 4  // slots of a scratch-tier program that live in LDS
+#define EVALH_LDS_HOT 4  // slots of a scratch-tier program that live in LDS (measured, 100 / 400 gates at 2^20 rows: 2 -> 13.1 / 38.7 ms,
+                         // 3 -> 11.9 / 38.3, 4 -> 11.5 / 36.3, 8 -> 12.2 / 40.7; all scratch: 14.6 / 45.4)
 __device__ __forceinline__ Fu lds_slot_get(uint32_t i) {
     Fu r;
 #pragma unroll
