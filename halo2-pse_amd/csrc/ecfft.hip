@@ -6,8 +6,8 @@
 // the reference's iterative form (arithmetic.rs:202-230: bit-reversal, then chunks 2, 4, ... n with
 // twiddles[i * twiddle_chunk]).  Between layers the points are brought back to affine by a batched inversion so that
 // every addition inside the scalar ladder is a mixed addition (9.2 vs 14 multiplications):
-//   ecfft_layer_kernel      t = [w] b by fixed 4-bit windows in the unsaturated XYZZ arithmetic of ecu.cuh (the
-//                           MSM's), the two closing additions in canonical ec.cuh arithmetic; layer 0 applies the
+//   ecfft_layer_kernel      t = [w] b by a GLV ladder (glv.cuh: w = w1 + w2 * LAMBDA, 2 + 2-bit joint windows) in the
+//                           unsaturated XYZZ arithmetic of ecu.cuh (the MSM's), the two closing additions in canonical ec.cuh arithmetic; layer 0 applies the
 //                           bit-reversal on its loads; butterflies with w = 1 skip the ladder (arithmetic.rs:255-260)
 //   ec_normalize_kernel     XYZZ -> affine, Montgomery's trick over 8 points per lane
 //   ec_scale_kernel         [n_inv] p for every point (wave-uniform scalar: no divergence), arithmetic.rs:286-290
@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include "engine.h"
+#include "glv.cuh"
 
 namespace h2 {
 
@@ -23,26 +24,41 @@ struct Scalar256 {
     uint32_t w[8];  // canonical integer, little-endian
 };
 
-// acc = [e] p for an affine p (E-form), e a canonical 254-bit integer: fixed 4-bit windows, MSB first.  The table
-// [1..15] p lives in per-lane scratch as XYZZ points (the digit differs per lane); per window 4 doublings and one
-// general addition -- 64 additions instead of the ~254 a wave of lanes with unrelated scalars executes under
-// double-and-add (every bit position has some lane with a one).
-__device__ XYZZu ec_mul_affine(const Affine& p, const Scalar256& e) {
+// acc = [k] p for an affine p (E-form) and a GLV-decomposed scalar k = k1 + k2 * LAMBDA: a joint ladder over |k1| and
+// |k2| (< 2^130) with p1 = +-p and p2 = +-phi(p) = +-(BETA * x, y), fixed 2 + 2-bit windows, MSB first.  The table
+// a * p1 + b * p2 (a, b < 4; 15 entries) lives in per-lane scratch as XYZZ points (the digits differ per lane); per window
+// 2 doublings and one general addition: 130 doublings + 65 additions against 252 + 63 for 4-bit windows over the full
+// scalar (and ~254 + 254 for a wave of lanes with unrelated scalars under plain double-and-add).
+__device__ XYZZu ec_mul_affine_glv(const Affine& p, const GlvScalar& k) {
     if (affine_is_identity(p)) return xyzzu_identity();
-    const Fu px = fu_from_ext(p.x), py = fu_from_ext(p.y);
-    XYZZu tab[16];
+    const uint32_t BETA_I[9] = {0x0a337995u, 0x158d1d23u, 0x189c9b98u, 0x12fa4e45u, 0x185faadcu, 0x0176f16du, 0x0eed93bau, 0x14291140u, 0x000c0afeu};
+    const Fu x1 = fu_from_ext(p.x);
+    Fu y1 = fu_from_ext(p.y), y2 = y1;
+    const Fu x2 = fu_mul<QU>(x1, fu_const<QU>(BETA_I));  // I-form of BETA * x, in (-0.2 q, 1.2 q)
+    if (k.neg1) y1 = fu_neg(y1);
+    if (k.neg2) y2 = fu_neg(y2);
+    XYZZu tab[16];  // tab[a + 4 b] = a * p1 + b * p2
     tab[0] = xyzzu_identity();
     tab[1] = xyzzu_identity();
-    xyzzu_add_mixed<QU>(tab[1], px, py);
-    tab[2] = xyzzu_double_affine<QU>(px, py);
-    for (int j = 3; j < 16; j++) {
-        tab[j] = tab[j - 1];
-        xyzzu_add_mixed<QU>(tab[j], px, py);
-    }
-    XYZZu acc = tab[e.w[7] >> 28];  // e < 2^254: the top nibble is at most 3
-    for (int i = 62; i >= 0; i--) {
-        acc = xyzzu_double(xyzzu_double(xyzzu_double(xyzzu_double(acc))));
-        const uint32_t d = (e.w[i >> 3] >> ((i & 7) * 4)) & 15;
+    xyzzu_add_mixed<QU>(tab[1], x1, y1);
+    tab[2] = xyzzu_double_affine<QU>(x1, y1);
+    tab[3] = tab[2];
+    xyzzu_add_mixed<QU>(tab[3], x1, y1);
+    tab[4] = xyzzu_identity();
+    xyzzu_add_mixed<QU>(tab[4], x2, y2);
+    tab[8] = xyzzu_double_affine<QU>(x2, y2);
+    tab[12] = tab[8];
+    xyzzu_add_mixed<QU>(tab[12], x2, y2);
+    for (int b = 1; b < 4; b++)
+        for (int a = 1; a < 4; a++) {
+            tab[a + 4 * b] = tab[a + 4 * (b - 1)];
+            xyzzu_add_mixed<QU>(tab[a + 4 * b], x2, y2);
+        }
+    XYZZu acc = xyzzu_identity();
+    for (int i = 64; i >= 0; i--) {
+        acc = xyzzu_double(xyzzu_double(acc));
+        const uint32_t d1 = (k.k1[i >> 4] >> ((i & 15) * 2)) & 3, d2 = (k.k2[i >> 4] >> ((i & 15) * 2)) & 3;
+        const uint32_t d = d1 | (d2 << 2);
         if (d) xyzzu_add(acc, tab[d]);
     }
     return acc;
@@ -63,7 +79,7 @@ __device__ XYZZu ec_mul_affine_uniform(const Affine& p, const Scalar256& e) {
 struct EcfftLayer {
     const Affine* in;
     XYZZ* out;
-    const Scalar256* tw;  // omega_inv^i, i < n / 2
+    const GlvScalar* tw;  // omega_inv^i, i < n / 2, decomposed
     uint32_t log_n, s;    // layer s: half = 2^s
 };
 
@@ -84,8 +100,8 @@ __global__ void __launch_bounds__(256) ecfft_layer_kernel(EcfftLayer L) {
     if (i == 0) {
         t = xyzz_from_affine(b);  // twiddle one
     } else {
-        const Scalar256 w = L.tw[i << (L.log_n - 1 - L.s)];  // twiddles[i * twiddle_chunk], twiddle_chunk = n / 2^(s+1)
-        t = xyzzu_to_ext(ec_mul_affine(b, w));
+        const GlvScalar w = L.tw[i << (L.log_n - 1 - L.s)];  // twiddles[i * twiddle_chunk], twiddle_chunk = n / 2^(s+1)
+        t = xyzzu_to_ext(ec_mul_affine_glv(b, w));
     }
     XYZZ hi = t, lo = t;
     lo.y = fe_neg<FqP>(t.y);
@@ -138,14 +154,11 @@ __global__ void __launch_bounds__(256) ec_normalize_kernel(const XYZZ* in, Affin
     }
 }
 
-__global__ void __launch_bounds__(256) ecfft_twiddle_kernel(Scalar256* tw, uint64_t count, Fe omega_inv) {
+__global__ void __launch_bounds__(256) ecfft_twiddle_kernel(GlvScalar* tw, uint64_t count, Fe omega_inv) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= count) return;
     const Fe c = fe_to_canonical<FrP>(fe_pow_u64<FrP>(omega_inv, tid));
-    Scalar256 o;
-#pragma unroll
-    for (int i = 0; i < 8; i++) o.w[i] = c.l[i];
-    tw[tid] = o;
+    tw[tid] = glv_decompose(c.l);
 }
 
 static int normalize_launch(const XYZZ* in, Affine* out, uint64_t n, hipStream_t s) {
@@ -163,12 +176,12 @@ int g_to_lagrange_device(Ctx* c, const Affine* d_g, uint32_t k, Affine* d_out, h
     }
     const uint64_t n = 1ull << k;
     // workspace: XYZZ[n] | twiddles[n / 2]; the affine points of the current layer live in d_out
-    const size_t xyzz_bytes = n * sizeof(XYZZ), tw_bytes = (n / 2 + 1) * sizeof(Scalar256);
+    const size_t xyzz_bytes = n * sizeof(XYZZ), tw_bytes = (n / 2 + 1) * sizeof(GlvScalar);
     int rc = c->ecfft_ws.ensure(xyzz_bytes + tw_bytes + 256);
     if (rc) return rc;
     if ((rc = c->ws_acquire(s))) return rc;
     XYZZ* d_xyzz = (XYZZ*)c->ecfft_ws.p;
-    Scalar256* d_tw = (Scalar256*)((char*)c->ecfft_ws.p + ((xyzz_bytes + 255) / 256) * 256);
+    GlvScalar* d_tw = (GlvScalar*)((char*)c->ecfft_ws.p + ((xyzz_bytes + 255) / 256) * 256);
     int tid = c->timer_begin("g_to_lagrange", s);
     // arithmetic.rs:278-282
     Fe omega_inv;

@@ -6,7 +6,10 @@
 #include <cstdlib>
 #include <vector>
 
+#include <cstring>
+
 #include "../../halo2-pse_amd/csrc/ecu.cuh"
+#include "../../halo2-pse_amd/csrc/glv.cuh"
 
 using namespace h2;
 
@@ -224,10 +227,66 @@ static void test_ec() {
     printf("ec fuzz done, failures so far %d\n", failures);
 }
 
+// glv.cuh: k == k1 + k2 * LAMBDA (mod r), |k1|, |k2| < 2^128, and [LAMBDA](x, y) == (BETA * x, y) on the curve
+static Fe fe_from_limbs5(const uint32_t v[5]) {
+    Fe c = fe_zero<FrP>();
+    for (int i = 0; i < 5; i++) c.l[i] = v[i];
+    return fe_from_canonical<FrP>(c);
+}
+static void test_glv() {
+    Fe lam_c = fe_zero<FrP>();
+    const uint32_t LAM[6] = {0xb99c90ddu, 0x8b17ea66u, 0x8d8daaa7u, 0x5bfc4108u, 0x41a91758u, 0xb3c4d79du};
+    for (int i = 0; i < 6; i++) lam_c.l[i] = LAM[i];
+    const Fe lam = fe_from_canonical<FrP>(lam_c);
+    int max_bits = 0;
+    for (int it = 0; it < 20000; it++) {
+        Fe k = rand_fe<FrP>(it < 8 ? it % 4 : 0);  // raw canonical integer < r
+        if (it == 8) k = lam_c;
+        GlvScalar g = glv_decompose(k.l);
+        CHECK(g.k1[4] < 4 && g.k2[4] < 4);  // < 2^130: the ladder reads 65 two-bit windows
+        for (int b = 159; b >= 0; b--)
+            if (((g.k1[b >> 5] >> (b & 31)) & 1) || ((g.k2[b >> 5] >> (b & 31)) & 1)) {
+                if (b + 1 > max_bits) max_bits = b + 1;
+                break;
+            }
+        Fe k1 = fe_from_limbs5(g.k1), k2 = fe_from_limbs5(g.k2);
+        if (g.neg1) k1 = fe_neg<FrP>(k1);
+        if (g.neg2) k2 = fe_neg<FrP>(k2);
+        Fe back = fe_add<FrP>(k1, fe_mul<FrP>(k2, lam));
+        Fe want = fe_from_canonical<FrP>(k);
+        CHECK(memcmp(back.l, want.l, 32) == 0);
+    }
+    printf("glv: max |k_i| = %d bits\n", max_bits);
+    CHECK(max_bits <= 128);
+    // the endomorphism: [LAMBDA] G == (BETA * 1, 2) for the generator G = (1, 2)
+    Affine G;
+    G.x = fe_one<FqP>();
+    G.y = fe_add<FqP>(fe_one<FqP>(), fe_one<FqP>());
+    XYZZ acc = xyzz_identity();
+    for (int b = 191; b >= 0; b--) {
+        acc = xyzz_double(acc);
+        if ((LAM[b >> 5] >> (b & 31)) & 1) xyzz_add_mixed(acc, G);
+    }
+    Affine got = xyzz_to_affine(acc);
+    Fe beta_c = fe_zero<FqP>();
+    const uint32_t BETA[6] = {0x77fffffeu, 0x57634731u, 0xacdb5c4fu, 0xd4f263f1u, 0xa0d48bacu, 0x59e26bceu};
+    for (int i = 0; i < 6; i++) beta_c.l[i] = BETA[i];
+    Fe beta = fe_from_canonical<FqP>(beta_c);
+    Fe bx = fe_mul<FqP>(beta, G.x);
+    CHECK(memcmp(got.x.l, bx.l, 32) == 0 && memcmp(got.y.l, G.y.l, 32) == 0);
+    // the I-form limbs of BETA that ecfft.hip hard-codes
+    const uint32_t BETA_I[9] = {0x0a337995u, 0x158d1d23u, 0x189c9b98u, 0x12fa4e45u, 0x185faadcu, 0x0176f16du, 0x0eed93bau, 0x14291140u, 0x000c0afeu};
+    Fe five = beta;  // E-form; I-form = E * 2^5
+    for (int i = 0; i < 5; i++) five = fe_dbl<FqP>(five);
+    Fu sl = fu_slice(five);
+    for (int i = 0; i < 9; i++) CHECK((uint32_t)sl.l[i] == BETA_I[i]);
+}
+
 int main() {
     test_field<FqU>("Fq");
     test_field<FrU>("Fr");
     test_ec();
+    test_glv();
     printf(failures ? "FIELDU TESTS FAILED (%d)\n" : "fieldu tests ok\n", failures);
     return failures ? 1 : 0;
 }
