@@ -356,9 +356,9 @@ static MsmPlan make_plan(size_t n, bool fused = false) {
         if (fused && lg >= 13 && lg <= 18) c = lg <= 13 ? 10 : lg <= 16 ? 12 : lg == 17 ? 13 : 14;
         else if (lg <= 8) c = 7;
         else if (lg <= 12) c = 10;
-        else if (lg <= 16) c = 13;
-        else if (lg <= 19) c = 15;
-        else c = 16;
+        else if (lg <= 15) c = 13;
+        else if (lg <= 18) c = 15;
+        else c = 16;  // re-swept after the sort went to two passes: 2^16 0.79 (c = 15) vs 0.83 ms (13); 2^19 1.43 (16) vs 1.53 ms (15)
     }
     if (c < 2) c = 2;
     if (c > 22) c = 22;
