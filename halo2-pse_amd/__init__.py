@@ -54,6 +54,10 @@ def lib():
         L.h2hip_version.restype = ctypes.c_char_p
         L.h2hip_get_msm_window.restype = ctypes.c_uint32
         L.h2hip_get_msm_window.argtypes = [ctypes.c_size_t]
+        L.h2hip_get_msm_window_fixed_base.restype = ctypes.c_uint32
+        L.h2hip_get_msm_window_fixed_base.argtypes = [ctypes.c_size_t]
+        L.h2hip_msm_min_n.restype = ctypes.c_size_t
+        L.h2hip_ntt_min_log_n.restype = ctypes.c_uint32
         _lib = L
     return _lib
 
@@ -80,11 +84,17 @@ def _fe(a):
 
 
 def init(device=None):
+    """device: None (HALO2_HIP_DEVICES or the current HIP device), one ordinal, or a list of ordinals (multi-GPU MSM)"""
     if device is None:
         _check(lib().h2hip_init(None, 0), "h2hip_init")
     else:
-        ids = (ctypes.c_int * 1)(int(device))
-        _check(lib().h2hip_init(ids, 1), "h2hip_init")
+        devs = [int(d) for d in device] if isinstance(device, (list, tuple)) else [int(device)]
+        ids = (ctypes.c_int * len(devs))(*devs)
+        _check(lib().h2hip_init(ids, len(devs)), "h2hip_init")
+
+
+def num_devices():
+    return int(lib().h2hip_num_devices())
 
 
 def shutdown():
@@ -162,6 +172,24 @@ def bases_pin(bases):
 
 def bases_unpin(bases):
     _check(lib().h2hip_bases_unpin(_p(bases)), "h2hip_bases_unpin")
+
+
+def bases_pin_device(d_bases, n=None):
+    """pin device-resident points (torch CUDA tensor): copies them and builds the fixed-base window table"""
+    n = d_bases.numel() * d_bases.element_size() // 64 if n is None else int(n)
+    _check(lib().h2hip_bases_pin_device(_dptr(d_bases), ctypes.c_size_t(n), _stream()), "h2hip_bases_pin_device")
+
+
+def bases_unpin_device(d_bases):
+    _check(lib().h2hip_bases_unpin(_dptr(d_bases)), "h2hip_bases_unpin")
+
+
+def bases_pinned_info(bases):
+    """(points, window bits, windows, bytes of HBM) of a pinned host array or device tensor"""
+    ptr = _p(bases) if isinstance(bases, np.ndarray) else _dptr(bases)
+    n, c, w, b = ctypes.c_size_t(0), ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_size_t(0)
+    _check(lib().h2hip_bases_pinned_info(ptr, ctypes.byref(n), ctypes.byref(c), ctypes.byref(w), ctypes.byref(b)), "h2hip_bases_pinned_info")
+    return n.value, c.value, w.value, b.value
 
 
 # ------------------------------------------------------------------ poly/domain.rs
@@ -266,11 +294,28 @@ class ParamsKZG:
         bases_pin(self.g_lagrange)
 
     def close(self):
-        for b in (self.g, self.g_lagrange):
+        """unpin both arrays (idempotent); also runs when the object is dropped or leaves a `with` block, so a dead
+        ParamsKZG never leaves its device copies behind under host addresses numpy may hand out again"""
+        for b in (getattr(self, "g", None), getattr(self, "g_lagrange", None)):
+            if b is None:
+                continue
             try:
                 bases_unpin(b)
             except H2HipError:
                 pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ------------------------------------------------------------------ device-resident entry points
@@ -373,6 +418,18 @@ def set_msm_window(c):
 
 def get_msm_window(n):
     return int(lib().h2hip_get_msm_window(n))
+
+
+def get_msm_window_fixed_base(n):
+    return int(lib().h2hip_get_msm_window_fixed_base(n))
+
+
+def msm_min_n():
+    return int(lib().h2hip_msm_min_n())
+
+
+def ntt_min_log_n():
+    return int(lib().h2hip_ntt_min_log_n())
 
 
 def profile_enable(on=True):

@@ -1,7 +1,14 @@
 // api.hip -- the extern "C" surface of libhalo2hip.so (include/halo2hip.h), the device
 // context, workspace buffers and HIP-event stage timers.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <condition_variable>
+#include <functional>
+#include <thread>
 
 #include "../../include/halo2hip.h"
 #include "engine.h"
@@ -12,6 +19,9 @@ int gen_scalars_device(uint64_t seed, uint64_t start, size_t n, Fe* d_out, hipSt
 int gen_points_device(uint64_t seed, uint64_t start, size_t n, Affine* d_out, hipStream_t s);
 void msm_set_window(uint32_t c);
 void msm_set_max_chunk(size_t m);
+void msm_set_heavy_div(size_t d);
+void msm_set_bin_entries(size_t d);
+void msm_set_l1_mode(int m);
 void ntt_set_smax(uint32_t v);
 void msm_set_reserved_cus(uint32_t k);
 uint32_t msm_get_reserved_cus();
@@ -76,8 +86,39 @@ void DevBuf::release() {
     cap = 0;
 }
 
+// ---- devices -----------------------------------------------------------------------------------------------------
+// One Ctx per device of h2hip_init's list.  g_ctx is the primary (device_ids[0]); its mutex serialises the entry
+// points.  The other devices only ever run MSM shards (best_multiexp splits its pairs the same way over rayon
+// threads, arithmetic.rs:137-153), each from its own worker thread.
 static Ctx g_ctx;
+static std::vector<Ctx*> g_devs;  // g_devs[0] == &g_ctx once ready
 Ctx* ctx() { return &g_ctx; }
+int n_devices() { return (int)g_devs.size(); }
+Ctx* ctx_at(int i) { return g_devs[(size_t)i]; }
+
+int Ctx::stage_h2d(void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
+    const size_t ring = (size_t)4 << 20;
+    if (bytes > ring / 2) {  // too large for the ring: a synchronous copy
+        H2_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s));
+        H2_CHECK(hipStreamSynchronize(s));
+        return 0;
+    }
+    if (!stage.p) {
+        int rc = stage.ensure(ring);
+        if (rc) return rc;
+        stage_off = 0;
+    }
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (stage_off + need > ring) {  // wrap: copies queued from the old contents must have left the ring
+        H2_CHECK(hipDeviceSynchronize());
+        stage_off = 0;
+    }
+    char* h = (char*)stage.p + stage_off;
+    memcpy(h, h_src, bytes);
+    stage_off += need;
+    H2_CHECK(hipMemcpyAsync(d_dst, h, bytes, hipMemcpyHostToDevice, s));
+    return 0;
+}
 
 int Ctx::timer_begin(const char* name, hipStream_t s) {
     if (!profiling) return -1;
@@ -179,27 +220,165 @@ int Ctx::ensure_aux(size_t n_events) {
     return 0;
 }
 
-static int do_init(const int* device_ids, int n_devices) {
-    Ctx* c = ctx();
-    std::lock_guard<std::recursive_mutex> lk(c->mu);
-    if (c->ready) return 0;
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0) {
-        set_error("no usable HIP device (%s); libhalo2hip has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
-        return H2HIP_EDEVICE;
+// ---- configuration (environment, read once at init) -----------------------------------------------------
+struct Config {
+    size_t multi_gpu_min_n = (size_t)1 << 18;  // HALO2_HIP_MULTI_GPU_MIN_N: smaller MSMs stay on the primary device
+    size_t msm_min_n = (size_t)1 << 10;        // HALO2_HIP_MSM_MIN_N: below this the Rust shim keeps the CPU body
+    uint32_t ntt_min_log_n = 10;               // HALO2_HIP_NTT_MIN_LOGN: likewise for best_fft
+    bool gather_rccl = true;                   // HALO2_HIP_GATHER=host|rccl: how the devices' partials meet
+    bool fixed_base = true;                    // HALO2_HIP_FIXED_BASE=0: h2hip_bases_pin keeps the points only
+    size_t table_max_bytes = (size_t)160 << 30;  // HALO2_HIP_TABLE_MAX_GB: largest window table built at pin time
+    bool allow_dup = false;                    // HALO2_HIP_ALLOW_DUPLICATE_DEVICES=1: rehearsal on a one-GPU box
+    bool roctx = false;                        // HALO2_HIP_ROCTX=1: roctx range around every entry point
+};
+static Config g_cfg;
+
+static bool env_u64(const char* name, uint64_t* out) {
+    const char* v = getenv(name);
+    if (!v || !*v) return false;
+    char* end = nullptr;
+    unsigned long long x = strtoull(v, &end, 0);
+    if (end == v) return false;
+    *out = x;
+    return true;
+}
+
+static void read_config() {
+    Config c;
+    uint64_t v;
+    if (env_u64("HALO2_HIP_MULTI_GPU_MIN_N", &v)) c.multi_gpu_min_n = (size_t)v;
+    if (env_u64("HALO2_HIP_MSM_MIN_N", &v)) c.msm_min_n = (size_t)v;
+    if (env_u64("HALO2_HIP_NTT_MIN_LOGN", &v)) c.ntt_min_log_n = (uint32_t)v;
+    if (env_u64("HALO2_HIP_FIXED_BASE", &v)) c.fixed_base = v != 0;
+    if (env_u64("HALO2_HIP_TABLE_MAX_GB", &v)) c.table_max_bytes = (size_t)v << 30;
+    if (env_u64("HALO2_HIP_ALLOW_DUPLICATE_DEVICES", &v)) c.allow_dup = v != 0;
+    if (env_u64("HALO2_HIP_ROCTX", &v)) c.roctx = v != 0;
+    if (env_u64("HALO2_HIP_MSM_WINDOW", &v) && v >= 2 && v <= 24) msm_set_window((uint32_t)v);
+    const char* g = getenv("HALO2_HIP_GATHER");
+    if (g && !strcmp(g, "host")) c.gather_rccl = false;
+    g_cfg = c;
+}
+
+// ---- roctx ranges (optional; the library is dlopen'ed so that nothing links against the tracer) ------------------------
+static int (*g_roctx_push)(const char*) = nullptr;
+static int (*g_roctx_pop)() = nullptr;
+static void roctx_load() {
+    if (g_roctx_push) return;
+    void* h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    g_roctx_push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+    g_roctx_pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!g_roctx_push || !g_roctx_pop) g_roctx_push = nullptr, g_roctx_pop = nullptr;
+}
+
+// ---- RCCL (dlopen'ed: a single-GPU consumer never needs it) ---------------------------------------------------------------
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::vector<ncclComm_t> comms;  // one per device of the engine, empty when the host gathers
+};
+static Rccl g_rccl;
+
+static bool rccl_load() {
+    Rccl& r = g_rccl;
+    if (r.lib) return true;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);  // the copy torch loaded, if any (same SONAME)
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return false;
+    r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) return false;
+    r.lib = h;
+    return true;
+}
+
+// ---- worker threads: one per secondary device, alive from init to shutdown -------------------------------------------------
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> task;
+    bool has_task = false, done = false, quit = false;
+    int rc = 0;
+    std::string err;
+};
+static std::vector<Worker*> g_workers;  // g_workers[i] serves g_devs[i]; [0] is unused (the caller's thread runs device 0)
+
+static void worker_main(Worker* w, int device) {
+    (void)hipSetDevice(device);
+    std::unique_lock<std::mutex> lk(w->m);
+    for (;;) {
+        w->cv.wait(lk, [&] { return w->has_task || w->quit; });
+        if (w->quit) return;
+        std::function<int()> t = std::move(w->task);
+        w->has_task = false;
+        lk.unlock();
+        g_err[0] = 0;
+        int rc = t();
+        lk.lock();
+        w->rc = rc;
+        w->err = g_err;
+        w->done = true;
+        w->cv.notify_all();
     }
-    int dev = 0;
-    if (device_ids && n_devices > 0) {
-        dev = device_ids[0];
-        if (dev < 0 || dev >= count) {
-            set_error("device id %d out of range (0..%d)", dev, count - 1);
-            return H2HIP_EINVAL;
-        }
-        H2_CHECK(hipSetDevice(dev));
+}
+
+static void worker_post(int i, std::function<int()> f) {
+    Worker* w = g_workers[(size_t)i];
+    std::lock_guard<std::mutex> lk(w->m);
+    w->task = std::move(f);
+    w->has_task = true;
+    w->done = false;
+    w->cv.notify_all();
+}
+
+static int worker_wait(int i) {
+    Worker* w = g_workers[(size_t)i];
+    std::unique_lock<std::mutex> lk(w->m);
+    w->cv.wait(lk, [&] { return w->done; });
+    if (w->rc) set_error("device %d: %s", g_devs[(size_t)i]->device, w->err.c_str());
+    return w->rc;
+}
+
+// Run f(i) for every engine device i < n_use: device 0 on the calling thread, the others on their workers.
+static int on_devices(int n_use, const std::function<int(int)>& f) {
+    for (int i = 1; i < n_use; i++) worker_post(i, [&f, i] { return f(i); });
+    int rc = 0;
+    if (hipSetDevice(g_devs[0]->device) != hipSuccess) {
+        set_error("hipSetDevice(%d) failed", g_devs[0]->device);
+        rc = H2HIP_EDEVICE;
     } else {
-        H2_CHECK(hipGetDevice(&dev));
+        rc = f(0);
     }
+    char first_err[sizeof(g_err)];
+    memcpy(first_err, g_err, sizeof(g_err));
+    for (int i = 1; i < n_use; i++) {
+        int r = worker_wait(i);
+        if (r && !rc) {
+            rc = r;
+            memcpy(first_err, g_err, sizeof(g_err));
+        }
+    }
+    if (rc) memcpy(g_err, first_err, sizeof(g_err));
+    return rc;
+}
+
+static bool unpin_everywhere(const void* key);
+static void pinned_validate(const uint64_t* bases_xy, size_t n);
+static const MsmTable* pinned_table(Ctx* c, const void* key, size_t n, const Affine** points, MsmTable* out);
+
+static int init_one(Ctx* c, int dev) {
+    H2_CHECK(hipSetDevice(dev));
     hipDeviceProp_t prop;
     H2_CHECK(hipGetDeviceProperties(&prop, dev));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -213,8 +392,98 @@ static int do_init(const int* device_ids, int n_devices) {
     return 0;
 }
 
+static void release_ctx(Ctx* c);
+
+static int do_init(const int* device_ids, int n_ids) {
+    Ctx* c = ctx();
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no usable HIP device (%s); libhalo2hip has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return H2HIP_EDEVICE;
+    }
+    read_config();
+    // the device list: the caller's, else HALO2_HIP_DEVICES ("0,1,2,3"), else the calling thread's current device
+    std::vector<int> ids;
+    if (device_ids && n_ids > 0) {
+        ids.assign(device_ids, device_ids + n_ids);
+    } else if (const char* v = getenv("HALO2_HIP_DEVICES")) {
+        for (const char* q = v; *q;) {
+            char* end = nullptr;
+            long d = strtol(q, &end, 10);
+            if (end == q) break;
+            ids.push_back((int)d);
+            q = *end == ',' ? end + 1 : end;
+            if (*end && *end != ',') break;
+        }
+    }
+    if (ids.empty()) {
+        int dev = 0;
+        H2_CHECK(hipGetDevice(&dev));
+        ids.push_back(dev);
+    }
+    if (c->ready) {  // idempotent for the same list; a different one needs h2hip_shutdown first
+        bool same = ids.size() == g_devs.size();
+        for (size_t i = 0; same && i < ids.size(); i++) same = g_devs[i]->device == ids[i];
+        if (same || !(device_ids && n_ids > 0)) return 0;
+        set_error("h2hip_init: already initialised with a different device list; call h2hip_shutdown first");
+        return H2HIP_EINVAL;
+    }
+    for (size_t i = 0; i < ids.size(); i++) {
+        if (ids[i] < 0 || ids[i] >= count) {
+            set_error("device id %d out of range (0..%d)", ids[i], count - 1);
+            return H2HIP_EINVAL;
+        }
+        for (size_t j = 0; j < i; j++)
+            if (ids[j] == ids[i] && !g_cfg.allow_dup) {
+                set_error("device id %d listed twice (HALO2_HIP_ALLOW_DUPLICATE_DEVICES=1 allows it for rehearsals)", ids[i]);
+                return H2HIP_EINVAL;
+            }
+    }
+    if (g_cfg.roctx) roctx_load();
+    g_devs.clear();
+    g_devs.push_back(c);
+    int rc = init_one(c, ids[0]);
+    for (size_t i = 1; !rc && i < ids.size(); i++) {
+        Ctx* x = new Ctx();
+        g_devs.push_back(x);
+        rc = init_one(x, ids[i]);
+    }
+    if (rc) {
+        for (size_t i = 0; i < g_devs.size(); i++) {
+            release_ctx(g_devs[i]);
+            if (i) delete g_devs[i];
+        }
+        g_devs.clear();
+        return rc;
+    }
+    (void)hipSetDevice(ids[0]);
+    // secondary devices: worker threads, and RCCL communicators for the gather of the partials (distinct devices only)
+    g_workers.assign(ids.size(), nullptr);
+    for (size_t i = 1; i < ids.size(); i++) {
+        g_workers[i] = new Worker();
+        g_workers[i]->th = std::thread(worker_main, g_workers[i], ids[i]);
+    }
+    bool distinct = true;
+    for (size_t i = 0; i < ids.size(); i++)
+        for (size_t j = 0; j < i; j++) distinct = distinct && ids[i] != ids[j];
+    if (ids.size() > 1 && g_cfg.gather_rccl && distinct && rccl_load()) {
+        g_rccl.comms.assign(ids.size(), nullptr);
+        ncclResult_t r = g_rccl.CommInitAll(g_rccl.comms.data(), (int)ids.size(), ids.data());
+        if (r != ncclSuccess) {  // not fatal: the host gathers the partials instead
+            set_error("ncclCommInitAll failed (%s); partials are gathered on the host", g_rccl.GetErrorString(r));
+            g_rccl.comms.clear();
+        }
+        (void)hipSetDevice(ids[0]);
+    }
+    return 0;
+}
+
 int ensure_init() {
-    if (ctx()->ready) return 0;
+    Ctx* c = ctx();
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (c->ready) return 0;
     return do_init(nullptr, 0);
 }
 
@@ -242,20 +511,48 @@ struct Entry {
     Ctx* c;
     std::unique_lock<std::recursive_mutex> lk;
     int rc;
-    Entry() : c(ctx()), rc(0) {
+    bool ranged = false;
+    // d_ptr: a device pointer of the call, or nullptr; with several devices the call runs on the device that owns it
+    explicit Entry(const char* name = nullptr, const void* d_ptr = nullptr) : c(ctx()), rc(0) {
         rc = ensure_init();
-        if (!rc) {
-            lk = std::unique_lock<std::recursive_mutex>(c->mu);
-            if (hipSetDevice(c->device) != hipSuccess) {
-                set_error("hipSetDevice(%d) failed", c->device);
-                rc = H2HIP_EDEVICE;
+        if (rc) return;
+        lk = std::unique_lock<std::recursive_mutex>(c->mu);
+        if (d_ptr && g_devs.size() > 1) {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, d_ptr) == hipSuccess) {
+                Ctx* owner = nullptr;
+                for (Ctx* x : g_devs)
+                    if (x->device == at.device) {
+                        owner = x;
+                        break;
+                    }
+                if (!owner) {
+                    set_error("device pointer belongs to device %d, which is not in h2hip_init's list", at.device);
+                    rc = H2HIP_EINVAL;
+                    return;
+                }
+                c = owner;
+            } else {
+                (void)hipGetLastError();
             }
         }
+        if (hipSetDevice(c->device) != hipSuccess) {
+            set_error("hipSetDevice(%d) failed", c->device);
+            rc = H2HIP_EDEVICE;
+            return;
+        }
+        if (name && g_roctx_push) {
+            g_roctx_push(name);
+            ranged = true;
+        }
+    }
+    ~Entry() {
+        if (ranged) g_roctx_pop();
     }
 };
 
 static int ntt_host(uint64_t* a, const Fe& omega, uint32_t log_n, const NttScale* sc, const uint64_t* src, size_t src_elems) {
-    Entry en;
+    Entry en("h2hip_ntt_host");
     if (en.rc) return en.rc;
     Ctx* c = en.c;
     size_t bytes = sizeof(Fe) << log_n;
@@ -289,20 +586,10 @@ static void make_zeta_scale(NttScale* sc, bool into_coset, const uint64_t g_cose
     }
 }
 
-}  // namespace h2
 
-using namespace h2;
-
-extern "C" {
-
-int h2hip_init(const int* device_ids, int n_devices) { return do_init(device_ids, n_devices); }
-
-void h2hip_shutdown(void) {
-    Ctx* c = ctx();
-    std::lock_guard<std::recursive_mutex> lk(c->mu);
-    if (!c->ready) return;
-    (void)hipSetDevice(c->device);
-    (void)hipDeviceSynchronize();
+static void release_ctx(Ctx* c) {
+    if (c->device >= 0) (void)hipSetDevice(c->device);
+    if (c->ready) (void)hipDeviceSynchronize();
     c->timers_collect();
     c->timers.clear();
     for (auto& kv : c->twiddles) {
@@ -320,12 +607,15 @@ void h2hip_shutdown(void) {
     }
     c->msm_bases.release();
     c->host_ws.release();
+    c->stage.release();
+    c->stage_off = 0;
     c->misc.release();
     c->evalh_ws.release();
     c->evalh_slots.release();
     c->ecfft_ws.release();
     c->ntt_ptrs.release();
-    (void)hipStreamDestroy(c->stream);
+    c->gather.release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = nullptr;
     for (auto e : c->aux_events) (void)hipEventDestroy(e);
     c->aux_events.clear();
@@ -339,8 +629,91 @@ void h2hip_shutdown(void) {
     c->ready = false;
 }
 
+// drop `key` from every device's pinned cache; true when it was there
+static bool unpin_everywhere(const void* key) {
+    bool found = false;
+    for (Ctx* x : g_devs) {
+        auto it = x->pinned.find(key);
+        if (it == x->pinned.end()) continue;
+        found = true;
+        (void)hipSetDevice(x->device);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(it->second.d);
+        x->pinned.erase(it);
+    }
+    if (!g_devs.empty()) (void)hipSetDevice(g_devs[0]->device);
+    return found;
+}
+
+// a host-keyed pinned entry is valid for this call only if n fits and the caller's array still carries the sampled
+// points; anything else is a stale entry and is dropped
+static void pinned_validate(const uint64_t* bases_xy, size_t n) {
+    Ctx* c = ctx();
+    auto it = c->pinned.find((const void*)bases_xy);
+    if (it == c->pinned.end() || it->second.device_key) return;
+    size_t total = 0;
+    for (Ctx* x : g_devs) {
+        auto jt = x->pinned.find((const void*)bases_xy);
+        if (jt != x->pinned.end() && jt->second.hi > total) total = jt->second.hi;
+    }
+    bool ok = n <= total;
+    if (ok) {
+        for (size_t k = 0; ok && k < H2_PIN_SAMPLES; k++) {
+            const size_t i = (size_t)((unsigned __int128)(total - 1) * k / (H2_PIN_SAMPLES - 1));
+            if (i < n || n == total) ok = memcmp(it->second.sample + 64 * k, bases_xy + 8 * i, 64) == 0;
+        }
+    }
+    if (!ok) (void)unpin_everywhere((const void*)bases_xy);
+}
+
+// window table of a device-pointer key on context c (h2hip_bases_pin_device), if n fits
+static const MsmTable* pinned_table(Ctx* c, const void* key, size_t n, const Affine** points, MsmTable* out) {
+    auto it = c->pinned.find(key);
+    if (it == c->pinned.end() || !it->second.device_key || n > it->second.n) return nullptr;
+    if (points) *points = (const Affine*)it->second.d;
+    if (!it->second.c) return nullptr;
+    out->table = (const Affine*)it->second.d;
+    out->stride = it->second.n;
+    out->c = it->second.c;
+    out->W = it->second.W;
+    return out;
+}
+
+}  // namespace h2
+
+using namespace h2;
+
+extern "C" {
+
+int h2hip_init(const int* device_ids, int n_devices) { return do_init(device_ids, n_devices); }
+
+void h2hip_shutdown(void) {
+    Ctx* c = ctx();
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (!c->ready) return;
+    for (size_t i = 1; i < g_workers.size(); i++) {
+        Worker* w = g_workers[i];
+        {
+            std::lock_guard<std::mutex> wl(w->m);
+            w->quit = true;
+            w->cv.notify_all();
+        }
+        w->th.join();
+        delete w;
+    }
+    g_workers.clear();
+    for (ncclComm_t cm : g_rccl.comms)
+        if (cm) (void)g_rccl.CommDestroy(cm);
+    g_rccl.comms.clear();
+    for (size_t i = g_devs.size(); i-- > 0;) {
+        release_ctx(g_devs[i]);
+        if (i) delete g_devs[i];
+    }
+    g_devs.clear();
+}
+
 const char* h2hip_last_error(void) { return g_err; }
-const char* h2hip_version(void) { return "halo2hip 0.1 (gfx950)"; }
+const char* h2hip_version(void) { return "halo2hip 0.2 (gfx950)"; }
 
 int h2hip_device_count(void) {
     int count = 0;
@@ -348,44 +721,157 @@ int h2hip_device_count(void) {
     return count;
 }
 
+int h2hip_num_devices(void) {
+    Ctx* c = ctx();
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    return c->ready ? (int)g_devs.size() : 0;
+}
+
+size_t h2hip_msm_min_n(void) {
+    (void)ensure_init();
+    return g_cfg.msm_min_n;
+}
+
+uint32_t h2hip_ntt_min_log_n(void) {
+    (void)ensure_init();
+    return g_cfg.ntt_min_log_n;
+}
+
 int h2hip_msm_bn254_device(const void* d_scalars, const void* d_bases_xy, size_t n, uint64_t out_xyz[12], void* stream) {
     if (!out_xyz || (n && (!d_scalars || !d_bases_xy))) {
         set_error("msm: null argument");
         return H2HIP_EINVAL;
     }
-    Entry en;
+    Entry en("h2hip_msm_bn254_device", d_scalars);
     if (en.rc) return en.rc;
     hipStream_t s = (hipStream_t)stream;
     XYZZ r;
-    int rc = msm_device(en.c, (const Fe*)d_scalars, (const Affine*)d_bases_xy, n, &r, s);
+    MsmTable tab;
+    const MsmTable* t = n ? pinned_table(en.c, d_bases_xy, n, nullptr, &tab) : nullptr;
+    int rc = msm_device(en.c, (const Fe*)d_scalars, (const Affine*)d_bases_xy, n, &r, s, t);
     if (rc) return rc;
     xyzz_to_out(r, out_xyz);
     return 0;
 }
 
+// `count` MSMs of n pairs with host-resident scalars on device context c: the bases come from c's pinned copy of
+// key[lo .. lo + n) when there is one (with its window table), else they are uploaded.
+static int msm_shard_host(Ctx* c, const uint64_t* const* scalars, const uint64_t* bases_xy, size_t lo, size_t n, size_t count, XYZZ* out) {
+    std::vector<const Fe*> sc(count);
+    for (size_t j = 0; j < count; j++) sc[j] = (const Fe*)scalars[j] + lo;
+    MsmTable tab;
+    const Affine* d_bases = nullptr;
+    const MsmTable* t = nullptr;
+    auto it = c->pinned.find((const void*)bases_xy);
+    if (it != c->pinned.end() && it->second.lo <= lo && lo + n <= it->second.hi) {
+        const PinnedBases& pb = it->second;
+        d_bases = (const Affine*)pb.d + (lo - pb.lo);
+        if (pb.c) {
+            tab.table = d_bases;
+            tab.stride = pb.n;
+            tab.c = pb.c;
+            tab.W = pb.W;
+            t = &tab;
+        }
+    } else {
+        int rc = c->msm_bases.ensure(n * sizeof(Affine));
+        if (rc) return rc;
+        H2_CHECK(hipMemcpyAsync(c->msm_bases.p, (const Affine*)bases_xy + lo, n * sizeof(Affine), hipMemcpyHostToDevice, c->stream));
+        d_bases = (const Affine*)c->msm_bases.p;
+    }
+    return msm_batch_device(c, sc.data(), true, d_bases, n, count, out, c->stream, t);
+}
+
+// The partials of the devices meet: RCCL all-gather of 96 B per (device, MSM) as bytes when the engine holds
+// communicators, through host memory otherwise; then the left fold of arithmetic.rs:153 on the host (a lone GPU lane
+// needs ~6 us per group addition, a host core 0.5 us).  parts: [device][count] on the host already.
+static int gather_fold(int n_use, size_t count, const std::vector<std::vector<XYZZ>>& parts, uint64_t* out_xyz) {
+    std::vector<Jac> all((size_t)n_use * count);
+    for (int d = 0; d < n_use; d++)
+        for (size_t j = 0; j < count; j++) all[(size_t)d * count + j] = xyzz_to_jac(parts[(size_t)d][j]);
+    if (!g_rccl.comms.empty() && n_use == (int)g_devs.size()) {
+        const size_t bytes = count * sizeof(Jac);
+        int rc = on_devices(n_use, [&](int d) -> int {
+            Ctx* x = g_devs[(size_t)d];
+            int r = x->gather.ensure(bytes * (size_t)(n_use + 1));
+            if (r) return r;
+            return x->stage_h2d(x->gather.p, &all[(size_t)d * count], bytes, x->stream);
+        });
+        if (rc) return rc;
+        ncclResult_t nr = g_rccl.GroupStart();
+        for (int d = 0; nr == ncclSuccess && d < n_use; d++) {
+            Ctx* x = g_devs[(size_t)d];
+            nr = g_rccl.AllGather(x->gather.p, (char*)x->gather.p + bytes, bytes, ncclUint8, g_rccl.comms[(size_t)d], x->stream);
+        }
+        ncclResult_t ne = g_rccl.GroupEnd();
+        if (nr == ncclSuccess) nr = ne;
+        if (nr != ncclSuccess) {
+            set_error("ncclAllGather failed: %s", g_rccl.GetErrorString(nr));
+            return H2HIP_EDEVICE;
+        }
+        Ctx* c0 = g_devs[0];
+        H2_CHECK(hipSetDevice(c0->device));
+        H2_CHECK(hipMemcpyAsync(all.data(), (char*)c0->gather.p + bytes, bytes * (size_t)n_use, hipMemcpyDeviceToHost, c0->stream));
+        H2_CHECK(hipStreamSynchronize(c0->stream));
+        for (int d = 1; d < n_use; d++) {  // every rank's collective has drained before the buffers are reused
+            H2_CHECK(hipSetDevice(g_devs[(size_t)d]->device));
+            H2_CHECK(hipStreamSynchronize(g_devs[(size_t)d]->stream));
+        }
+        H2_CHECK(hipSetDevice(c0->device));
+    }
+    for (size_t j = 0; j < count; j++) {
+        XYZZ acc = xyzz_identity();
+        for (int d = 0; d < n_use; d++) xyzz_add(acc, jac_to_xyzz(all[(size_t)d * count + j]));
+        xyzz_to_out(acc, out_xyz + 12 * j);
+    }
+    return 0;
+}
+
 static int msm_host_common(const uint64_t* const* scalars, const uint64_t* bases_xy, size_t n, size_t count, uint64_t* out_xyz) {
-    Entry en;
+    Entry en("h2hip_msm_bn254");
     if (en.rc) return en.rc;
     Ctx* c = en.c;
     if (n == 0 || count == 0) {
         for (size_t j = 0; j < count; j++) xyzz_to_out(xyzz_identity(), out_xyz + 12 * j);
         return 0;
     }
-    const Affine* d_bases = nullptr;
-    auto it = c->pinned.find((const void*)bases_xy);
-    if (it != c->pinned.end() && it->second.n >= n) {
-        d_bases = (const Affine*)it->second.d;
-    } else {
-        int rc = c->msm_bases.ensure(n * sizeof(Affine));
+    // a pinned entry whose fingerprint no longer matches the caller's array is stale (the allocation was freed and
+    // reused): drop it on every device and fall back to uploading
+    pinned_validate(bases_xy, n);
+    const int nd = (int)g_devs.size();
+    if (nd == 1 || n < g_cfg.multi_gpu_min_n) {
+        std::vector<XYZZ> r(count);
+        int rc = msm_shard_host(c, scalars, bases_xy, 0, n, count, r.data());
         if (rc) return rc;
-        H2_CHECK(hipMemcpyAsync(c->msm_bases.p, bases_xy, n * sizeof(Affine), hipMemcpyHostToDevice, c->stream));
-        d_bases = (const Affine*)c->msm_bases.p;
+        for (size_t j = 0; j < count; j++) xyzz_to_out(r[j], out_xyz + 12 * j);
+        return 0;
     }
-    std::vector<XYZZ> r(count);
-    int rc = msm_batch_device(c, (const Fe* const*)scalars, true, d_bases, n, count, r.data(), c->stream);
+    // Several devices: contiguous ranges of pairs per device, as best_multiexp chunks them over threads
+    // (arithmetic.rs:137-152).  Pinned bases fix the partition (each device holds its range and its window table).
+    std::vector<size_t> lo((size_t)nd), hi((size_t)nd);
+    auto it0 = c->pinned.find((const void*)bases_xy);
+    if (it0 != c->pinned.end()) {
+        for (int d = 0; d < nd; d++) {
+            auto it = g_devs[(size_t)d]->pinned.find((const void*)bases_xy);
+            size_t l = it != g_devs[(size_t)d]->pinned.end() ? it->second.lo : n, h = it != g_devs[(size_t)d]->pinned.end() ? it->second.hi : n;
+            lo[(size_t)d] = l < n ? l : n;
+            hi[(size_t)d] = h < n ? h : n;
+        }
+    } else {
+        const size_t per = n / (size_t)nd;
+        for (int d = 0; d < nd; d++) {
+            lo[(size_t)d] = (size_t)d * per;
+            hi[(size_t)d] = d == nd - 1 ? n : (size_t)(d + 1) * per;
+        }
+    }
+    std::vector<std::vector<XYZZ>> parts((size_t)nd, std::vector<XYZZ>(count, xyzz_identity()));
+    int rc = on_devices(nd, [&](int d) -> int {
+        const size_t m = hi[(size_t)d] - lo[(size_t)d];
+        if (!m) return 0;
+        return msm_shard_host(g_devs[(size_t)d], scalars, bases_xy, lo[(size_t)d], m, count, parts[(size_t)d].data());
+    });
     if (rc) return rc;
-    for (size_t j = 0; j < count; j++) xyzz_to_out(r[j], out_xyz + 12 * j);
-    return 0;
+    return gather_fold(nd, count, parts, out_xyz);
 }
 
 int h2hip_msm_bn254(const uint64_t* scalars, const uint64_t* bases_xy, size_t n, uint64_t out_xyz[12]) {
@@ -419,13 +905,79 @@ int h2hip_msm_bn254_batch_device(const void* const* d_scalars, const void* d_bas
             set_error("msm_batch: d_scalars[%zu] is null", j);
             return H2HIP_EINVAL;
         }
-    Entry en;
+    Entry en("h2hip_msm_bn254_batch_device", count ? d_scalars[0] : nullptr);
     if (en.rc) return en.rc;
     std::vector<XYZZ> r(count);
-    int rc = msm_batch_device(en.c, (const Fe* const*)d_scalars, false, (const Affine*)d_bases_xy, n, count, r.data(), (hipStream_t)stream);
+    MsmTable tab;
+    const MsmTable* t = (n && count) ? pinned_table(en.c, d_bases_xy, n, nullptr, &tab) : nullptr;
+    int rc = msm_batch_device(en.c, (const Fe* const*)d_scalars, false, (const Affine*)d_bases_xy, n, count, r.data(), (hipStream_t)stream, t);
     if (rc) return rc;
     for (size_t j = 0; j < count; j++) xyzz_to_out(r[j], out_xyz + 12 * j);
     return 0;
+}
+
+// Pin points [lo, hi) of the caller's array on device context c (worker thread of that device, or the caller's for
+// device 0): device copy + window table.  d_src != nullptr: the points already live on this device.
+static int pin_on_device(Ctx* c, const void* key, const uint64_t* h_points, const void* d_src, size_t lo, size_t hi, size_t n_total,
+                         const uint8_t* sample, bool device_key) {
+    (void)n_total;
+    auto it = c->pinned.find(key);
+    if (it != c->pinned.end()) {
+        H2_CHECK(hipDeviceSynchronize());
+        (void)hipFree(it->second.d);
+        c->pinned.erase(it);
+    }
+    if (hi <= lo) return 0;
+    const size_t n = hi - lo;
+    PinnedBases pb;
+    pb.n = n;
+    pb.lo = lo;
+    pb.hi = hi;
+    pb.device_key = device_key;
+    if (sample) memcpy(pb.sample, sample, sizeof(pb.sample));
+    uint32_t cw = 0, W = 1;
+    if (g_cfg.fixed_base && n >= 16 && n <= ((size_t)1 << 26)) {
+        cw = msm_table_window(n);
+        W = (255 + cw - 1) / cw;
+        if ((size_t)W * n * sizeof(Affine) > g_cfg.table_max_bytes) cw = 0, W = 1;
+    }
+    hipError_t e = hipMalloc(&pb.d, (size_t)W * n * sizeof(Affine));
+    if (e != hipSuccess && cw) {  // no room for the table: keep the points only
+        (void)hipGetLastError();
+        cw = 0;
+        W = 1;
+        e = hipMalloc(&pb.d, n * sizeof(Affine));
+    }
+    if (e != hipSuccess) {
+        set_error("bases_pin: hipMalloc(%zu) failed: %s", (size_t)W * n * sizeof(Affine), hipGetErrorString(e));
+        return H2HIP_ENOMEM;
+    }
+    int rc = 0;
+    if (d_src) {
+        if (!cw) H2_CHECK(hipMemcpyAsync(pb.d, (const Affine*)d_src + lo, n * sizeof(Affine), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        H2_CHECK(hipMemcpyAsync(pb.d, (const Affine*)h_points + lo, n * sizeof(Affine), hipMemcpyHostToDevice, c->stream));
+    }
+    if (cw) rc = msm_table_build(c, d_src ? (const Affine*)d_src + lo : (const Affine*)pb.d, n, cw, (Affine*)pb.d, c->stream);
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) {
+        set_error("bases_pin: table build failed");
+        rc = H2HIP_EDEVICE;
+    }
+    if (rc) {
+        (void)hipFree(pb.d);
+        return rc;
+    }
+    pb.c = cw;
+    pb.W = cw ? W : 0;
+    c->pinned[key] = pb;
+    return 0;
+}
+
+static void pin_sample(const uint64_t* bases_xy, size_t n, uint8_t* out) {
+    for (size_t k = 0; k < H2_PIN_SAMPLES; k++) {
+        const size_t i = H2_PIN_SAMPLES > 1 ? (size_t)((unsigned __int128)(n - 1) * k / (H2_PIN_SAMPLES - 1)) : 0;
+        memcpy(out + 64 * k, bases_xy + 8 * i, 64);
+    }
 }
 
 int h2hip_bases_pin(const uint64_t* bases_xy, size_t n) {
@@ -433,39 +985,64 @@ int h2hip_bases_pin(const uint64_t* bases_xy, size_t n) {
         set_error("bases_pin: null/empty");
         return H2HIP_EINVAL;
     }
-    Entry en;
+    Entry en("h2hip_bases_pin");
     if (en.rc) return en.rc;
-    Ctx* c = en.c;
-    auto it = c->pinned.find((const void*)bases_xy);
-    if (it != c->pinned.end()) {
-        H2_CHECK(hipDeviceSynchronize());
-        (void)hipFree(it->second.d);
-        c->pinned.erase(it);
-    }
-    PinnedBases pb;
-    pb.n = n;
-    hipError_t e = hipMalloc(&pb.d, n * sizeof(Affine));
-    if (e != hipSuccess) {
-        set_error("bases_pin: hipMalloc(%zu) failed: %s", n * sizeof(Affine), hipGetErrorString(e));
-        return H2HIP_ENOMEM;
-    }
-    H2_CHECK(hipMemcpy(pb.d, bases_xy, n * sizeof(Affine), hipMemcpyHostToDevice));
-    c->pinned[(const void*)bases_xy] = pb;
-    return 0;
+    uint8_t sample[H2_PIN_SAMPLES * 64];
+    pin_sample(bases_xy, n, sample);
+    const int nd = (int)g_devs.size();
+    const int use = n >= g_cfg.multi_gpu_min_n ? nd : 1;
+    const size_t per = n / (size_t)use;
+    int rc = on_devices(nd, [&](int d) -> int {
+        size_t lo = d < use ? (size_t)d * per : n, hi = d < use ? (d == use - 1 ? n : (size_t)(d + 1) * per) : n;
+        return pin_on_device(g_devs[(size_t)d], (const void*)bases_xy, bases_xy, nullptr, lo, hi, n, sample, false);
+    });
+    if (rc) (void)unpin_everywhere((const void*)bases_xy);
+    return rc;
 }
 
-int h2hip_bases_unpin(const uint64_t* bases_xy) {
-    Entry en;
+int h2hip_bases_pin_device(const void* d_bases_xy, size_t n, void* stream) {
+    if (!d_bases_xy || !n) {
+        set_error("bases_pin_device: null/empty");
+        return H2HIP_EINVAL;
+    }
+    Entry en("h2hip_bases_pin_device", d_bases_xy);
     if (en.rc) return en.rc;
-    Ctx* c = en.c;
-    auto it = c->pinned.find((const void*)bases_xy);
-    if (it == c->pinned.end()) {
+    H2_CHECK(hipStreamSynchronize((hipStream_t)stream));  // the points may have been produced on the caller's stream
+    return pin_on_device(en.c, d_bases_xy, nullptr, d_bases_xy, 0, n, n, nullptr, true);
+}
+
+int h2hip_bases_unpin(const void* bases_xy) {
+    Entry en("h2hip_bases_unpin");
+    if (en.rc) return en.rc;
+    if (!unpin_everywhere(bases_xy)) {
         set_error("bases_unpin: pointer was not pinned");
         return H2HIP_EINVAL;
     }
-    H2_CHECK(hipDeviceSynchronize());
-    (void)hipFree(it->second.d);
-    c->pinned.erase(it);
+    return 0;
+}
+
+int h2hip_bases_pinned_info(const void* bases_xy, size_t* n_points, uint32_t* window_bits, uint32_t* windows, size_t* device_bytes) {
+    Entry en;
+    if (en.rc) return en.rc;
+    size_t n = 0, bytes = 0;
+    uint32_t c = 0, W = 0;
+    bool found = false;
+    for (Ctx* x : g_devs) {
+        auto it = x->pinned.find(bases_xy);
+        if (it == x->pinned.end()) continue;
+        found = true;
+        n += it->second.n;
+        bytes += (size_t)(it->second.c ? it->second.W : 1) * it->second.n * sizeof(Affine);
+        if (it->second.c) c = it->second.c, W = it->second.W;
+    }
+    if (!found) {
+        set_error("bases_pinned_info: pointer is not pinned");
+        return H2HIP_EINVAL;
+    }
+    if (n_points) *n_points = n;
+    if (window_bits) *window_bits = c;
+    if (windows) *windows = W;
+    if (device_bytes) *device_bytes = bytes;
     return 0;
 }
 
@@ -523,7 +1100,7 @@ int h2hip_device_alloc(size_t bytes, void** d_ptr) {
         set_error("device_alloc: null argument");
         return H2HIP_EINVAL;
     }
-    Entry en;
+    Entry en("h2hip_device_alloc");
     if (en.rc) return en.rc;
     hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
     if (e != hipSuccess) {
@@ -535,7 +1112,7 @@ int h2hip_device_alloc(size_t bytes, void** d_ptr) {
 }
 
 int h2hip_device_free(void* d_ptr) {
-    Entry en;
+    Entry en("h2hip_device_free", d_ptr);
     if (en.rc) return en.rc;
     H2_CHECK(hipDeviceSynchronize());
     H2_CHECK(hipFree(d_ptr));
@@ -547,7 +1124,7 @@ int h2hip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream)
         set_error("memcpy_h2d: null argument");
         return H2HIP_EINVAL;
     }
-    Entry en;
+    Entry en("h2hip_memcpy_h2d", d_dst);
     if (en.rc) return en.rc;
     H2_CHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     H2_CHECK(hipStreamSynchronize((hipStream_t)stream));  // the source is a borrowed host slice
@@ -559,7 +1136,7 @@ int h2hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream)
         set_error("memcpy_d2h: null argument");
         return H2HIP_EINVAL;
     }
-    Entry en;
+    Entry en("h2hip_memcpy_d2h", d_src);
     if (en.rc) return en.rc;
     H2_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     H2_CHECK(hipStreamSynchronize((hipStream_t)stream));
@@ -571,14 +1148,14 @@ int h2hip_memset_zero(void* d_dst, size_t bytes, void* stream) {
         set_error("memset_zero: null argument");
         return H2HIP_EINVAL;
     }
-    Entry en;
+    Entry en("h2hip_memset_zero", d_dst);
     if (en.rc) return en.rc;
     H2_CHECK(hipMemsetAsync(d_dst, 0, bytes, (hipStream_t)stream));
     return 0;
 }
 
 int h2hip_stream_synchronize(void* stream) {
-    Entry en;
+    Entry en("h2hip_stream_synchronize");
     if (en.rc) return en.rc;
     H2_CHECK(hipStreamSynchronize((hipStream_t)stream));
     return 0;
@@ -602,7 +1179,7 @@ int h2hip_ntt_bn254_fr_device(void* d_a, const uint64_t omega[4], uint32_t log_n
         return H2HIP_EINVAL;
     }
     if (check_fr(omega, "omega")) return H2HIP_EINVAL;
-    Entry en;
+    Entry en("h2hip_ntt_bn254_fr_device", d_a);
     if (en.rc) return en.rc;
     hipStream_t s = (hipStream_t)stream;
     return ntt_device(en.c, (Fe*)d_a, fe_from_u64x4(omega), log_n, nullptr, s);
@@ -623,7 +1200,7 @@ int h2hip_ifft_bn254_fr_device(void* d_a, const uint64_t omega_inv[4], uint32_t 
         return H2HIP_EINVAL;
     }
     if (check_fr(omega_inv, "omega_inv") || check_fr(divisor, "divisor")) return H2HIP_EINVAL;
-    Entry en;
+    Entry en("h2hip_ifft_bn254_fr_device", d_a);
     if (en.rc) return en.rc;
     hipStream_t s = (hipStream_t)stream;
     NttScale sc;
@@ -651,7 +1228,7 @@ int h2hip_coeff_to_extended_bn254_fr_device(void* d_a, uint32_t k, uint32_t exte
         return H2HIP_EINVAL;
     }
     if (check_fr(extended_omega, "extended_omega") || check_fr(g_coset, "g_coset") || check_fr(g_coset_inv, "g_coset_inv")) return H2HIP_EINVAL;
-    Entry en;
+    Entry en("h2hip_coeff_to_extended_bn254_fr_device", d_a);
     if (en.rc) return en.rc;
     hipStream_t s = (hipStream_t)stream;
     NttScale sc;
@@ -683,7 +1260,7 @@ int h2hip_extended_to_coeff_bn254_fr_device(void* d_a, uint32_t extended_k, cons
     if (check_fr(extended_omega_inv, "extended_omega_inv") || check_fr(extended_ifft_divisor, "extended_ifft_divisor") ||
         check_fr(g_coset, "g_coset") || check_fr(g_coset_inv, "g_coset_inv"))
         return H2HIP_EINVAL;
-    Entry en;
+    Entry en("h2hip_extended_to_coeff_bn254_fr_device", d_a);
     if (en.rc) return en.rc;
     hipStream_t s = (hipStream_t)stream;
     NttScale sc;
@@ -714,7 +1291,7 @@ int h2hip_divide_by_vanishing_poly_bn254_fr_device(void* d_a, uint32_t extended_
     }
     for (uint32_t i = 0; i < t_len; i++)
         if (check_fr(t_evaluations + 4 * i, "t_evaluations[i]")) return H2HIP_EINVAL;
-    Entry en;
+    Entry en("h2hip_divide_by_vanishing_poly_bn254_fr_device", d_a);
     if (en.rc) return en.rc;
     return scale_periodic_device(en.c, (Fe*)d_a, 1ull << extended_k, t_evaluations, t_len, (hipStream_t)stream);
 }
@@ -726,7 +1303,7 @@ int h2hip_divide_by_vanishing_poly_bn254_fr(uint64_t* a, uint32_t extended_k, co
     }
     for (uint32_t i = 0; i < t_len; i++)
         if (check_fr(t_evaluations + 4 * i, "t_evaluations[i]")) return H2HIP_EINVAL;
-    Entry en;
+    Entry en("h2hip_divide_by_vanishing_poly_bn254_fr");
     if (en.rc) return en.rc;
     Ctx* c = en.c;
     size_t bytes = sizeof(Fe) << extended_k;
@@ -757,7 +1334,7 @@ static int batch_args_ok(void* const* d_a, size_t count, uint32_t log_n, const c
 int h2hip_ntt_bn254_fr_batch_device(void* const* d_a, size_t count, const uint64_t omega[4], uint32_t log_n, void* stream) {
     if (!omega || !batch_args_ok(d_a, count, log_n, "ntt_batch")) return H2HIP_EINVAL;
     if (check_fr(omega, "omega")) return H2HIP_EINVAL;
-    Entry en;
+    Entry en("h2hip_ntt_bn254_fr_batch_device", count ? d_a[0] : nullptr);
     if (en.rc) return en.rc;
     return ntt_device_batch(en.c, (Fe* const*)d_a, nullptr, count, fe_from_u64x4(omega), log_n, nullptr, (hipStream_t)stream);
 }
@@ -766,7 +1343,7 @@ int h2hip_ifft_bn254_fr_batch_device(void* const* d_a, size_t count, const uint6
                                      void* stream) {
     if (!omega_inv || !divisor || !batch_args_ok(d_a, count, log_n, "ifft_batch")) return H2HIP_EINVAL;
     if (check_fr(omega_inv, "omega_inv") || check_fr(divisor, "divisor")) return H2HIP_EINVAL;
-    Entry en;
+    Entry en("h2hip_ifft_bn254_fr_batch_device", count ? d_a[0] : nullptr);
     if (en.rc) return en.rc;
     NttScale sc;
     sc.out_scale = true;
@@ -779,7 +1356,7 @@ int h2hip_coeff_to_extended_bn254_fr_batch_device(void* const* d_a, size_t count
     if (!extended_omega || !g_coset || !g_coset_inv || k > extended_k || !batch_args_ok(d_a, count, extended_k, "coeff_to_extended_batch"))
         return H2HIP_EINVAL;
     if (check_fr(extended_omega, "extended_omega") || check_fr(g_coset, "g_coset") || check_fr(g_coset_inv, "g_coset_inv")) return H2HIP_EINVAL;
-    Entry en;
+    Entry en("h2hip_coeff_to_extended_bn254_fr_batch_device", count ? d_a[0] : nullptr);
     if (en.rc) return en.rc;
     NttScale sc;
     make_zeta_scale(&sc, true, g_coset, g_coset_inv, nullptr);
@@ -792,7 +1369,7 @@ int h2hip_g_to_lagrange_bn254_device(const void* d_g_xy, uint32_t k, void* d_g_l
         set_error("g_to_lagrange: bad argument");
         return H2HIP_EINVAL;
     }
-    Entry en;
+    Entry en("h2hip_g_to_lagrange_bn254_device", d_g_xy);
     if (en.rc) return en.rc;
     return g_to_lagrange_device(en.c, (const Affine*)d_g_xy, k, (Affine*)d_g_lagrange_xy, (hipStream_t)stream);
 }
@@ -802,7 +1379,7 @@ int h2hip_g_to_lagrange_bn254(const uint64_t* g_xy, uint32_t k, uint64_t* g_lagr
         set_error("g_to_lagrange: bad argument");
         return H2HIP_EINVAL;
     }
-    Entry en;
+    Entry en("h2hip_g_to_lagrange_bn254");
     if (en.rc) return en.rc;
     Ctx* c = en.c;
     const size_t bytes = sizeof(Affine) << k;
@@ -824,7 +1401,7 @@ int h2hip_evaluate_h_bn254(const h2hip_evalh_desc* desc, uint64_t* values) {
         return H2HIP_EINVAL;
     }
     if (evaluate_h_validate(desc, values)) return H2HIP_EINVAL;
-    Entry en;
+    Entry en("h2hip_evaluate_h_bn254");
     if (en.rc) return en.rc;
     return evaluate_h_host(en.c, desc, values, false, en.c->stream);
 }
@@ -835,7 +1412,7 @@ int h2hip_evaluate_h_bn254_device(const h2hip_evalh_desc* desc, void* d_values, 
         return H2HIP_EINVAL;
     }
     if (evaluate_h_validate(desc, d_values)) return H2HIP_EINVAL;
-    Entry en;
+    Entry en("h2hip_evaluate_h_bn254_device", d_values);
     if (en.rc) return en.rc;
     return evaluate_h_host(en.c, desc, (uint64_t*)d_values, true, (hipStream_t)stream);
 }
@@ -845,7 +1422,7 @@ int h2hip_gen_scalars_device(uint64_t seed, uint64_t start, size_t n, void* d_ou
         set_error("gen_scalars: null output");
         return H2HIP_EINVAL;
     }
-    Entry en;
+    Entry en("h2hip_gen_scalars_device", d_out);
     if (en.rc) return en.rc;
     return gen_scalars_device(seed, start, n, (Fe*)d_out, (hipStream_t)stream);
 }
@@ -855,14 +1432,14 @@ int h2hip_gen_points_device(uint64_t seed, uint64_t start, size_t n, void* d_out
         set_error("gen_points: null output");
         return H2HIP_EINVAL;
     }
-    Entry en;
+    Entry en("h2hip_gen_points_device", d_out);
     if (en.rc) return en.rc;
     return gen_points_device(seed, start, n, (Affine*)d_out, (hipStream_t)stream);
 }
 
 int h2hip_set_msm_window(uint32_t c) {
-    if (c != 0 && (c < 2 || c > 22)) {
-        set_error("msm window must be 0 (auto) or 2..22");
+    if (c != 0 && (c < 2 || c > 24)) {
+        set_error("msm window must be 0 (auto) or 2..24");
         return H2HIP_EINVAL;
     }
     msm_set_window(c);
@@ -870,10 +1447,28 @@ int h2hip_set_msm_window(uint32_t c) {
 }
 
 uint32_t h2hip_get_msm_window(size_t n) { return msm_get_window(n); }
+uint32_t h2hip_get_msm_window_fixed_base(size_t n) { return msm_table_window(n); }
 
 // test hook: split inputs above m pairs into consecutive chunks (default 2^26, the 31-bit pair-index limit)
 int h2hip_debug_set_msm_max_chunk(size_t m) {
     msm_set_max_chunk(m);
+    return 0;
+}
+
+// tuning hook: buckets above (entries of the MSM) / d go to the chunked path (default 32768; 0 restores it)
+int h2hip_debug_set_msm_heavy_div(size_t d) {
+    msm_set_heavy_div(d);
+    return 0;
+}
+
+int h2hip_debug_set_msm_l1_mode(int m) {
+    msm_set_l1_mode(m);
+    return 0;
+}
+
+// tuning hook: target number of entries per coarse bin of the MSM's two-level sort (default 8192; 0 restores it)
+int h2hip_debug_set_msm_bin_entries(size_t d) {
+    msm_set_bin_entries(d);
     return 0;
 }
 

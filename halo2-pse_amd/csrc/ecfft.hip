@@ -168,6 +168,8 @@ static int normalize_launch(const XYZZ* in, Affine* out, uint64_t n, hipStream_t
     return 0;
 }
 
+int ec_normalize_device(const XYZZ* d_in, Affine* d_out, uint64_t n, hipStream_t s) { return normalize_launch(d_in, d_out, n, s); }
+
 // d_g: n affine points in (read only); d_out: n affine points out.  Queued on s; does not wait.
 int g_to_lagrange_device(Ctx* c, const Affine* d_g, uint32_t k, Affine* d_out, hipStream_t s) {
     if (k > FrP::S) {

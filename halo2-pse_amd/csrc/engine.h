@@ -58,9 +58,24 @@ struct TwiddleTable {
     uint32_t lo_bits = 0;
 };
 
+// Fixed-base window table of a pinned base array (msm.hip): row j (of `stride` points) = 2^(c j) * P, j < W
+struct MsmTable {
+    const Affine* table = nullptr;
+    size_t stride = 0;
+    uint32_t c = 0, W = 0;
+};
+
+#define H2_PIN_SAMPLES 16
+// One entry of the pinned-bases cache, keyed by the caller's pointer (host or device).
 struct PinnedBases {
-    void* d = nullptr;
-    size_t n = 0;
+    void* d = nullptr;         // device copy: W x n points with the window table, or n points without one
+    size_t n = 0;              // points per row
+    uint32_t c = 0, W = 0;     // window width of the table; 0: no table (rows = 1)
+    bool device_key = false;   // the key is a device pointer (h2hip_bases_pin_device): no fingerprint check
+    // fingerprint of the host array at pin time: H2_PIN_SAMPLES points (first, last, evenly spread), compared byte for
+    // byte on every lookup -- a freed-and-reused allocation at the same address must not hit the stale copy
+    uint8_t sample[H2_PIN_SAMPLES * 64];
+    size_t lo = 0, hi = 0;     // multi-GPU: this device holds points [lo, hi) of the caller's array (n = hi - lo)
 };
 
 struct StageTimer {
@@ -76,8 +91,13 @@ struct Ctx {
     bool ready = false;
     hipStream_t stream = nullptr;  // the engine's own stream (host-pointer entry points)
     std::recursive_mutex mu;       // serialises entry points: re-entrant callers (rayon workers) are safe
-    DevBuf ntt_ws, ntt_io, msm_scalars[3], msm_bases, msm_slot[3], misc, evalh_ws, evalh_slots, ecfft_ws, ntt_ptrs;
+    DevBuf ntt_ws, ntt_io, msm_scalars[3], msm_bases, msm_slot[3], misc, evalh_ws, evalh_slots, ecfft_ws, ntt_ptrs, gather;
     HostBuf host_ws;               // pinned host memory for the window sums coming back
+    // Small host tables the kernels read (pointer lists, constants) go through this pinned ring, so that the
+    // asynchronous copy never reads a caller's stack or a std::vector that is gone by the time the DMA runs.
+    HostBuf stage;
+    size_t stage_off = 0;
+    int stage_h2d(void* d_dst, const void* h_src, size_t bytes, hipStream_t s);
     std::map<TwiddleKey, TwiddleTable> twiddles;
     std::map<const void*, PinnedBases> pinned;
     // profiling
@@ -102,8 +122,10 @@ struct Ctx {
     int ensure_aux(size_t n_events);
 };
 
-Ctx* ctx();             // the process-wide context (one process per GPU)
-int ensure_init();      // lazily h2hip_init(NULL, 0)
+Ctx* ctx();             // the primary device's context (device_ids[0] of h2hip_init)
+int n_devices();        // devices the engine was initialised with (>= 1 once ready)
+Ctx* ctx_at(int i);     // context of the i-th device of h2hip_init's list
+int ensure_init();      // lazily h2hip_init(NULL, 0), or the HALO2_HIP_DEVICES list
 
 // ntt.hip
 struct NttScale {
@@ -125,6 +147,7 @@ int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const uint64_t* h_t, uint
 
 // ecfft.hip
 int g_to_lagrange_device(Ctx* c, const Affine* d_g, uint32_t k, Affine* d_out, hipStream_t s);
+int ec_normalize_device(const XYZZ* d_in, Affine* d_out, uint64_t n, hipStream_t s);  // batched XYZZ -> affine
 
 // evalh.hip
 void evalh_debug_set_max_local_slots(uint32_t v);
@@ -134,8 +157,11 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
 
 // msm.hip
 void msm_set_fuse_small(bool on);
-int msm_device(Ctx* c, const Fe* d_scalars, const Affine* d_bases, size_t n, XYZZ* h_out, hipStream_t s);
+// tab != nullptr: fixed-base form over tab's window table (d_bases unused)
+int msm_device(Ctx* c, const Fe* d_scalars, const Affine* d_bases, size_t n, XYZZ* h_out, hipStream_t s, const MsmTable* tab = nullptr);
 int msm_batch_device(Ctx* c, const Fe* const* scalars, bool scalars_on_host, const Affine* d_bases, size_t n, size_t count, XYZZ* h_out,
-                     hipStream_t s);
+                     hipStream_t s, const MsmTable* tab = nullptr);
+uint32_t msm_table_window(size_t n);  // window width a table for n pinned points is built with
+int msm_table_build(Ctx* c, const Affine* d_points, size_t n, uint32_t cw, Affine* d_table, hipStream_t s);
 
 }  // namespace h2

@@ -7,18 +7,31 @@
 // only the group element is defined (SURVEY.md App. B rule 3), and that is what this engine
 // reproduces bit-exactly after normalisation to affine.
 //
-// GPU schedule (one stream, no host sync until the W window sums come back):
-//   K1 msm_digits_kernel     to_repr + get_at (arithmetic.rs:14,24-42): Montgomery -> canonical,
-//                            signed c-bit digits; emits (bucket key, point index | sign) pairs
-//   sort                     radix sort of the pairs by key (rocPRIM via hipCUB)
-//   K2a msm_bounds_kernel    bucket -> [start, end) in the sorted pairs
-//   K2  msm_accum_kernel     one lane per bucket: XYZZ mixed adds over its pairs (arithmetic.rs:84-89);
-//                            over-full buckets (skewed scalars) go to a chunk list
-//   K2h msm_heavy_*          workgroup-per-chunk accumulation + LDS tree for over-full buckets
-//   K3  msm_reduce1/2        summation by parts (arithmetic.rs:95-99), segmented: per-lane running
-//                            sums over 2^s buckets, then one workgroup per window
-//   K4  host                 Horner over the W window sums with c doublings each (arithmetic.rs:46-49)
-#include <hipcub/hipcub.hpp>
+// Two forms of the same pipeline:
+//   plain        the W windows of an MSM have one bucket set each (2^(c-1) signed-digit buckets); the window sums
+//                come back to the host, which finishes with the Horner of arithmetic.rs:46-49.
+//   fixed-base   for bases that live as long as a ParamsKZG (g, g_lagrange: poly/kzg/commitment.rs:26-27) the
+//                engine keeps the table 2^(c j) * P_i, j < W, in HBM (built once by h2hip_bases_pin*).  Digit j of
+//                scalar i then selects table[j][i], every window adds into the SAME bucket set, the windows can
+//                be wide (c = 20 at 2^20 pairs: W = 13 instead of 16 bucket additions per pair) and the one set
+//                sum IS the result: no Horner.
+//
+// GPU schedule (one stream, no host sync until the set sums come back):
+//   A  msm_l1_kernel<count>    to_repr + get_at (arithmetic.rs:14,24-42): Montgomery -> canonical, signed c-bit
+//                              digits; per-workgroup LDS histogram over coarse bins (bucket id >> L)
+//      msm_l1_scan_kernel      exclusive scan of the coarse-bin sizes
+//      msm_l1_kernel<scatter>  digits again; a workgroup reserves its share of every coarse bin with one atomic
+//                              per bin and writes (entry, bucket id) there
+//      msm_l2_kernel           one workgroup per coarse bin: LDS counting sort on the low L bits -> entries grouped
+//                              by bucket, bucket start / size, size-class histogram
+//      msm_bucket_scatter      buckets ordered by size, so the 64 lanes of a wave get equal-length buckets
+//   B  msm_accum_kernel        one lane per bucket: XYZZ mixed adds over its entries (arithmetic.rs:84-89);
+//      msm_heavy_*             workgroup-per-chunk accumulation + LDS tree for over-full buckets
+//   C  msm_rowcol_kernel       summation by parts (arithmetic.rs:95-99) restated as plain sums: with the bucket
+//                              index b = hi * 2^s + lo,  sum (b+1) B_b = 2^s sum hi R_hi + sum (lo+1) C_lo  for the
+//                              row sums R and column sums C; applied twice, then
+//      msm_final_kernel        <= 256 small multiples + one tree per bucket set
+//   D  host                    plain form only: Horner over the W set sums with c doublings each
 #include <string.h>
 
 #include <vector>
@@ -28,98 +41,307 @@
 
 namespace h2 {
 
-#define MSM_MAX_WINDOWS 64
+#define MSM_MAX_C1 1024u   // coarse bins of the level-1 pass
+#define MSM_MAX_L 12u      // low bucket-id bits sorted by the level-2 pass (LDS histogram of 2^L counters)
+#define MSM_STAGE 16384u   // entries of one LDS-staged tile (level 1: 128 KB of (entry, bucket); level 2: 96 KB)
+#define MSM_COUNT_TILE 4096u  // scalars per workgroup of the count pass
 
+// Windows: the 255 bits a signed-digit recoding of a scalar < 2^254 needs are cut into W = ceil(255 / c) windows, the
+// first q of them c bits wide and the rest c - 1, q = 255 - W (c - 1).  With equal widths the top window would hold only
+// 254 mod c bits: its n digits would crowd into 2^(254 mod c) buckets (64 extra entries in each of 2^14 buckets at
+// c = 20, n = 2^20), and the lanes of those buckets would set the duration of the accumulation.
 struct MsmPlan {
-    uint32_t c;        // window bits
+    uint32_t c;        // window bits (wide windows)
     uint32_t W;        // number of windows
-    uint32_t NB;       // buckets per window = 2^(c-1)
-    uint32_t log_s1;   // level-1 segment = 2^log_s1 buckets per lane
+    uint32_t q;        // windows 0..q-1 are c bits wide, windows q..W-1 are c - 1
+    uint32_t cb;       // c - 1
+    uint32_t NB;       // buckets per set = 2^(c-1)
+    uint32_t shared;   // fixed-base form: the windows share one bucket set
     uint32_t heavy_t;  // bucket size above which the chunked path is used
-    uint32_t chunk;    // pairs per heavy chunk
+    uint32_t chunk;    // entries per heavy chunk
 };
 
-__device__ __forceinline__ uint32_t scalar_bits(const Fe& s, uint32_t bit, uint32_t c) {
-    uint32_t limb = bit >> 5, sh = bit & 31;
-    if (limb >= 8) return 0;
-    uint64_t lo = s.l[limb];
-    uint64_t hi = (limb + 1 < 8) ? s.l[limb + 1] : 0;
-    return (uint32_t)(((lo | (hi << 32)) >> sh) & ((1u << c) - 1));
-}
-
-// K1: one lane per scalar
-// A fused batch launches it once with gridDim.y = MSMs: MSM y reads list[y] and writes windows [y * W, (y + 1) * W).
-__global__ void __launch_bounds__(256) msm_digits_kernel(const Fe* __restrict__ scalars_one, const Fe* const* __restrict__ list, uint32_t n, uint32_t c,
-                                                         uint32_t W, uint32_t NB, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const Fe* __restrict__ scalars = list ? list[blockIdx.y] : scalars_one;
-    const uint32_t w_base = blockIdx.y * W;
-    Fe s = fe_to_canonical<FrP>(scalars[i]);
-    uint32_t carry = 0;
-    const uint32_t half = 1u << (c - 1);
-    // key = (window << c) | slot, slot = |digit| - 1 in [0, NB) or NB for a zero digit (skipped): pairs are
-    // written window-major, so each window's n pairs can also be sorted on their own on the low c bits
-    for (uint32_t w = 0; w < W; w++) {
-        uint32_t d = scalar_bits(s, w * c, c) + carry;
+// get_at (arithmetic.rs:24-42) with signed digits: f(window, |digit| - 1, negative) for every non-zero digit.
+// The limbs are walked with compile-time indices through a 64-bit bit buffer (a run-time limb index would put the
+// scalar into scratch memory); c <= 24, so the buffer never holds more than 23 + 32 bits.
+template <class F>
+__device__ __forceinline__ void for_each_digit(const Fe& s, uint32_t c, uint32_t q, uint32_t W, F&& f) {
+    uint64_t buf = 0;
+    uint32_t nb = 0, w = 0, carry = 0;
+    uint32_t width = q ? c : c - 1;
+    auto emit = [&]() {
+        uint32_t d = ((uint32_t)buf & ((1u << width) - 1)) + carry;
         uint32_t neg = 0;
         carry = 0;
-        if (d > half) {
-            d = (1u << c) - d;
+        if (d > (1u << (width - 1))) {
+            d = (1u << width) - d;
             neg = 1;
             carry = 1;
         }
-        size_t e = (size_t)(w_base + w) * n + i;
-        keys[e] = ((w_base + w) << c) | (d ? d - 1 : NB);
-        vals[e] = i | (neg << 31);
+        if (d) f(w, d - 1, neg);
+        w++;
+        buf >>= width;
+        nb = nb > width ? nb - width : 0;
+        width = w < q ? c : c - 1;
+    };
+#pragma unroll
+    for (int limb = 0; limb < 8; limb++) {
+        buf |= (uint64_t)s.l[limb] << nb;
+        nb += 32;
+        while (nb >= width && w < W) emit();
     }
+    while (w < W) emit();  // the bits left over (zero-extended) and any windows above them
 }
 
-// K2a: bucket bounds by boundary detection over the sorted keys (coalesced, no searches): the lane that sees
-// a key change records where the new key's run starts and where the previous key's run ended.  start/end are
-// zeroed beforehand, so an empty bucket reads as [0, 0).
-__global__ void __launch_bounds__(256) msm_bounds_kernel(const uint32_t* __restrict__ keys, size_t e_begin, size_t e_end, uint32_t c,
-                                                         uint32_t* __restrict__ start, uint32_t* __restrict__ end) {
-    const uint32_t NB = 1u << (c - 1), slot_mask = (1u << c) - 1;
-    for (size_t i = e_begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < e_end; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t k = keys[i];
-        const bool first = (i == e_begin);
-        const uint32_t kp = first ? 0xffffffffu : keys[i - 1];
-        if (first || kp != k) {
-            if ((k & slot_mask) < NB) start[((k >> c) << (c - 1)) | (k & slot_mask)] = (uint32_t)i;
-            if (!first && (kp & slot_mask) < NB) end[((kp >> c) << (c - 1)) | (kp & slot_mask)] = (uint32_t)i;
+struct L1Args {
+    const Fe* scalars_one;
+    const Fe* const* list;  // fused batch: MSM y reads list[y]
+    uint32_t n, c, q, W, cb, L, C1;
+    uint32_t shared, stride;  // fixed-base: entry index = window * stride + pair
+    uint32_t tile;                // scalars per workgroup of the scatter pass
+    uint32_t* g_cnt;              // [C1] coarse-bin sizes (count pass)
+    const uint32_t* coarse_start; // [C1 + 1] (scatter pass)
+    uint32_t* g_cursor;           // [C1] entries already reserved per coarse bin (scatter pass)
+    uint2* tmp;                   // (entry, bucket id) grouped by coarse bin
+};
+
+// PrimeField::to_repr (arithmetic.rs:14) on the unsaturated multiplier: the stored a * 2^256 times 32, divided by the
+// Montgomery radix 2^261 and reduced exactly -- ~220 instructions instead of the ~535 of the saturated CIOS
+__device__ __forceinline__ Fe fr_to_canonical(const Fe& x) {
+    Fu c32 = fu_zero();
+    c32.l[0] = 32;
+    return fu_mul_canon<FrU>(fu_slice(x), c32);
+}
+
+// A1: sizes of the coarse bins.  Bucket id of (MSM y, window w, slot) = (set << cb) | slot with set = y (fixed-base)
+// or y * W + w; coarse bin = bucket id >> L.
+__global__ void __launch_bounds__(256) msm_l1_count_kernel(L1Args a) {
+    __shared__ uint32_t lh[MSM_MAX_C1];
+    for (uint32_t b = threadIdx.x; b < a.C1; b += 256) lh[b] = 0;
+    __syncthreads();
+    const Fe* __restrict__ scalars = a.list ? a.list[blockIdx.y] : a.scalars_one;
+    const uint32_t set0 = a.shared ? blockIdx.y : blockIdx.y * a.W;
+    const uint32_t i0 = blockIdx.x * MSM_COUNT_TILE + threadIdx.x;
+    for (uint32_t t = 0; t < MSM_COUNT_TILE / 256; t++) {
+        const uint32_t i = i0 + t * 256;
+        if (i < a.n) {
+            const Fe sc = fr_to_canonical(scalars[i]);
+            for_each_digit(sc, a.c, a.q, a.W, [&](uint32_t w, uint32_t slot, uint32_t) {
+                const uint32_t gb = ((set0 + (a.shared ? 0u : w)) << a.cb) | slot;
+                atomicAdd(&lh[gb >> a.L], 1u);
+            });
         }
-        if (i + 1 == e_end && (k & slot_mask) < NB) end[((k >> c) << (c - 1)) | (k & slot_mask)] = (uint32_t)(i + 1);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < a.C1; b += 256)
+        if (lh[b]) atomicAdd(&a.g_cnt[b], lh[b]);
+}
+
+// exclusive scan of cnt[0..n) over a workgroup of BS lanes (n <= per * BS): lane t owns elements [t * per, (t + 1) * per).
+// Returns this lane's first offset; ps is BS words of LDS scratch; *total gets the sum.
+template <int BS>
+__device__ __forceinline__ uint32_t block_scan_base(const uint32_t* cnt, uint32_t n, uint32_t per, uint32_t* ps, uint32_t* total) {
+    const uint32_t t = threadIdx.x;
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < per; j++) {
+        const uint32_t k = t * per + j;
+        if (k < n) sum += cnt[k];
+    }
+    // inclusive scan inside the wave with lane shuffles, then over the BS / 64 wave totals through LDS
+    uint32_t inc = sum;
+#pragma unroll
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(inc, off, 64);
+        if ((t & 63) >= off) inc += up;
+    }
+    if ((t & 63) == 63) ps[t >> 6] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < BS / 64; w++) {
+        const uint32_t v = ps[w];
+        if (w < (t >> 6)) before += v;
+        all += v;
+    }
+    __syncthreads();
+    *total = all;
+    return before + inc - sum;
+}
+
+// A3: one scalar per lane (the first a.tile lanes).  The workgroup sorts its entries by coarse bin in LDS and writes
+// every bin's share as one contiguous run.  What bounds this pass is how HBM takes the writes: with 3-entry runs (or a
+// scattered 8-byte store per entry) every run is a partial-line write and the pass ran at 0.6 TB/s; hence at most
+// MSM_MAX_C1 bins for a tile of up to MSM_STAGE entries.  One returning global atomic per (workgroup, bin) reserves
+// the run's place.
+__global__ void __launch_bounds__(1024) msm_l1_scatter_kernel(L1Args a) {
+    __shared__ uint2 stage[MSM_STAGE];
+    __shared__ uint32_t cur[MSM_MAX_C1];   // entries per bin, then the bin's cursor in `stage`
+    __shared__ uint32_t delta[MSM_MAX_C1]; // (position in tmp) - (position in stage) of the bin's run (mod 2^32)
+    __shared__ uint32_t ps[16];
+    for (uint32_t b = threadIdx.x; b < a.C1; b += 1024) cur[b] = 0;
+    __syncthreads();
+    const Fe* __restrict__ scalars = a.list ? a.list[blockIdx.y] : a.scalars_one;
+    const uint32_t set0 = a.shared ? blockIdx.y : blockIdx.y * a.W;
+    const uint32_t i = blockIdx.x * a.tile + threadIdx.x;
+    const bool live = threadIdx.x < a.tile && i < a.n;
+    Fe sc;
+    if (live) {
+        sc = fr_to_canonical(scalars[i]);
+        for_each_digit(sc, a.c, a.q, a.W, [&](uint32_t w, uint32_t slot, uint32_t) {
+            const uint32_t gb = ((set0 + (a.shared ? 0u : w)) << a.cb) | slot;
+            atomicAdd(&cur[gb >> a.L], 1u);
+        });
+    }
+    __syncthreads();
+    uint32_t total;
+    uint32_t run = block_scan_base<1024>(cur, a.C1, 1, ps, &total);  // C1 <= 1024: one bin per lane
+    if (threadIdx.x < a.C1) {
+        const uint32_t b = threadIdx.x, cnt = cur[b];
+        if (cnt) delta[b] = a.coarse_start[b] + atomicAdd(&a.g_cursor[b], cnt) - run;
+        cur[b] = run;
+    }
+    __syncthreads();
+    if (live) {
+        for_each_digit(sc, a.c, a.q, a.W, [&](uint32_t w, uint32_t slot, uint32_t neg) {
+            const uint32_t gb = ((set0 + (a.shared ? 0u : w)) << a.cb) | slot;
+            const uint32_t pos = atomicAdd(&cur[gb >> a.L], 1u);
+            stage[pos] = make_uint2((a.shared ? w * a.stride + i : i) | (neg << 31), gb);
+        });
+    }
+    __syncthreads();
+    for (uint32_t pos = threadIdx.x; pos < total; pos += 1024) {
+        const uint2 e = stage[pos];
+        a.tmp[pos + delta[e.y >> a.L]] = e;
     }
 }
 
-// K2b/K2c: order the buckets by size (descending, in 256 classes of width 2^bin_shift) with a counting sort, so that
-// the 64 lanes of an accumulate wave get buckets of near-equal size.  hist[0..256) = class counts, hist[256..512)
-// = per-class cursors; both zeroed beforehand.
+// A2: coarse_start = exclusive scan of the C1 <= 1024 coarse-bin sizes; one workgroup of 1024
+__global__ void __launch_bounds__(1024) msm_l1_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t C1, uint32_t* __restrict__ coarse_start) {
+    __shared__ uint32_t ps[16];
+    uint32_t total;
+    const uint32_t run = block_scan_base<1024>(cnt, C1, 1, ps, &total);
+    if (threadIdx.x < C1) coarse_start[threadIdx.x] = run;
+    if (threadIdx.x == 0) coarse_start[C1] = total;
+}
+
+// size classes of the accumulate order: 256 classes of width 2^bin_shift entries, big buckets first
 __device__ __forceinline__ uint32_t size_class(uint32_t cnt, uint32_t bin_shift) {
     uint32_t b = cnt >> bin_shift;
-    return 255u - (b < 255u ? b : 255u);  // big buckets first
+    return 255u - (b < 255u ? b : 255u);
 }
 
-__global__ void __launch_bounds__(256) msm_bucket_hist_kernel(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end, uint32_t gb_base,
-                                                              uint32_t n_buckets, uint32_t bin_shift, uint32_t* __restrict__ counts,
-                                                              uint32_t* __restrict__ hist) {
-    __shared__ uint32_t lh[256];
-    lh[threadIdx.x] = 0;
+// A4: one workgroup per coarse bin -- counting sort of its entries on the low L bits of the bucket id, through LDS, one
+// tile of MSM_STAGE entries at a time (16 per lane, held in registers between the tile's count and its placement);
+// every bucket's share of a tile leaves as one contiguous run.  A bin of at most one tile is read from HBM once, a
+// larger one twice (count, place).  Also writes, for the bin's 2^L buckets: start / counts (empty buckets included) and
+// the accumulate order -- the bin's buckets by descending size class, so that the 64 lanes of an accumulate wave (which
+// takes 64 consecutive entries of perm) get buckets of equal length.
+__global__ void __launch_bounds__(1024) msm_l2_kernel(const uint2* __restrict__ tmp, const uint32_t* __restrict__ coarse_start, uint32_t L,
+                                                      uint32_t bin_shift, uint32_t* __restrict__ vals, uint32_t* __restrict__ start,
+                                                      uint32_t* __restrict__ counts, uint32_t* __restrict__ perm, uint32_t* __restrict__ class_hist) {
+    constexpr uint32_t NBMAX = 1u << MSM_MAX_L, EPT = MSM_STAGE / 1024;
+    __shared__ uint32_t sval[MSM_STAGE];
+    __shared__ uint16_t skey[MSM_STAGE];
+    __shared__ uint32_t gpos[NBMAX];    // where the bucket's next entry goes in vals
+    __shared__ uint32_t tcur[NBMAX];    // entries of the tile per bucket, then the bucket's cursor in the staged tile
+    __shared__ uint32_t tdelta[NBMAX];  // (position in vals) - (position in the staged tile) of the bucket's run
+    __shared__ uint32_t ps[16], cls[256];
+    const uint32_t nb = 1u << L, t = threadIdx.x, per = (nb + 1023) / 1024;
+    const uint32_t cs = coarse_start[blockIdx.x], ce = coarse_start[blockIdx.x + 1];
+    const bool single = ce - cs <= MSM_STAGE;
+    for (uint32_t k = t; k < nb; k += 1024) tcur[k] = 0;
+    if (t < 256) cls[t] = 0;
     __syncthreads();
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_buckets) {
-        uint32_t gb = gb_base + t;
-        uint32_t cnt = end[gb] - start[gb];
-        counts[gb] = cnt;
-        atomicAdd(&lh[size_class(cnt, bin_shift)], 1u);
+    uint2 e[EPT];
+    if (single) {
+#pragma unroll
+        for (uint32_t j = 0; j < EPT; j++) {
+            const uint32_t idx = cs + t + j * 1024;
+            if (idx < ce) {
+                e[j] = tmp[idx];
+                atomicAdd(&tcur[e[j].y & (nb - 1)], 1u);
+            }
+        }
+    } else {
+        for (uint32_t idx = cs + t; idx < ce; idx += 1024) atomicAdd(&tcur[tmp[idx].y & (nb - 1)], 1u);
     }
     __syncthreads();
-    if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+    uint32_t total;
+    uint32_t run = block_scan_base<1024>(tcur, nb, per, ps, &total);
+    const uint32_t gb0 = blockIdx.x << L;
+    for (uint32_t j = 0; j < per; j++) {
+        const uint32_t k = t * per + j;
+        if (k < nb) {
+            const uint32_t cnt = tcur[k];
+            gpos[k] = cs + run;
+            start[gb0 + k] = cs + run;
+            counts[gb0 + k] = cnt;
+            atomicAdd(&cls[size_class(cnt, bin_shift)], 1u);
+            run += cnt;
+        }
+    }
+    __syncthreads();
+    if (class_hist) {
+        if (t < 256 && cls[t]) atomicAdd(&class_hist[t], cls[t]);
+    } else {
+        // the bin's buckets in descending size-class order: exclusive scan of the 256 class counts (tdelta is free here)
+        uint32_t dummy;
+        const uint32_t c0 = block_scan_base<1024>(cls, 256, 1, ps, &dummy);
+        if (t < 256) tdelta[t] = c0;
+        __syncthreads();
+        for (uint32_t j = 0; j < per; j++) {
+            const uint32_t k = t * per + j;
+            if (k < nb) perm[gb0 + atomicAdd(&tdelta[size_class(tcur[k], bin_shift)], 1u)] = gb0 + k;
+        }
+        __syncthreads();
+    }
+    for (uint32_t base = cs; base < ce; base += MSM_STAGE) {
+        const uint32_t tile_n = ce - base < MSM_STAGE ? ce - base : MSM_STAGE;
+        if (!single) {
+            for (uint32_t k = t; k < nb; k += 1024) tcur[k] = 0;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t j = 0; j < EPT; j++) {
+                const uint32_t idx = t + j * 1024;
+                if (idx < tile_n) {
+                    e[j] = tmp[base + idx];
+                    atomicAdd(&tcur[e[j].y & (nb - 1)], 1u);
+                }
+            }
+            __syncthreads();
+        }
+        run = block_scan_base<1024>(tcur, nb, per, ps, &total);
+        for (uint32_t j = 0; j < per; j++) {
+            const uint32_t k = t * per + j;
+            if (k < nb) {
+                const uint32_t cnt = tcur[k];
+                tdelta[k] = gpos[k] - run;
+                gpos[k] += cnt;
+                tcur[k] = run;
+                run += cnt;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < EPT; j++) {
+            const uint32_t idx = t + j * 1024;
+            if (idx < tile_n) {
+                const uint32_t k = e[j].y & (nb - 1);
+                const uint32_t pos = atomicAdd(&tcur[k], 1u);
+                sval[pos] = e[j].x;
+                skey[pos] = (uint16_t)k;
+            }
+        }
+        __syncthreads();
+        for (uint32_t pos = t; pos < tile_n; pos += 1024) vals[pos + tdelta[skey[pos]]] = sval[pos];
+        __syncthreads();
+    }
 }
 
-__global__ void __launch_bounds__(256) msm_bucket_scatter_kernel(const uint32_t* __restrict__ counts, uint32_t gb_base, uint32_t n_buckets,
-                                                                 uint32_t bin_shift, uint32_t* __restrict__ hist, uint32_t* __restrict__ perm) {
+// A5: order the buckets by size (descending, 256 classes) with a counting sort.  hist[0..256) = class counts (from
+// msm_l2_kernel), hist[256..512) = per-class cursors, zeroed beforehand.
+__global__ void __launch_bounds__(256) msm_bucket_scatter_kernel(const uint32_t* __restrict__ counts, uint32_t n_buckets, uint32_t bin_shift,
+                                                                 uint32_t* __restrict__ hist, uint32_t* __restrict__ perm) {
     __shared__ uint32_t scan[256], lh[256], lbase[256];
     // exclusive scan of the 256 class counts (every block repeats it: 256 values)
     uint32_t v = hist[threadIdx.x];
@@ -139,13 +361,13 @@ __global__ void __launch_bounds__(256) msm_bucket_scatter_kernel(const uint32_t*
     uint32_t cls = 0, rank = 0;
     const bool live = t < n_buckets;
     if (live) {
-        cls = size_class(counts[gb_base + t], bin_shift);
+        cls = size_class(counts[t], bin_shift);
         rank = atomicAdd(&lh[cls], 1u);
     }
     __syncthreads();
     if (lh[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&hist[256 + threadIdx.x], lh[threadIdx.x]);
     __syncthreads();
-    if (live) perm[scan[cls] + lbase[cls] + rank] = gb_base + t;
+    if (live) perm[scan[cls] + lbase[cls] + rank] = t;
 }
 
 struct HeavyBucket {
@@ -155,14 +377,14 @@ struct HeavyChunk {
     uint32_t begin, end;
 };
 
-// one bucket-accumulation step: acc += (+/-) bases[index], in the unsaturated arithmetic of ecu.cuh
+// one bucket-accumulation step: acc += (+/-) points[index], in the unsaturated arithmetic of ecu.cuh
 template <class F>
 __device__ __forceinline__ void accum_signed(XYZZu& acc, const Affine* __restrict__ bases, uint32_t v) {
     Affine p = bases[v & 0x7fffffffu];
     xyzzu_add_affine<F>(acc, p, (v >> 31) != 0);
 }
 
-// K2: one lane per bucket
+// B: one lane per bucket.  `bases` is the caller's point array (plain form) or the window table (fixed-base form).
 __global__ void __launch_bounds__(256) msm_accum_kernel(const Affine* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                         const uint32_t* __restrict__ start, const uint32_t* __restrict__ counts,
                                                         const uint32_t* __restrict__ perm, uint32_t n_buckets, uint32_t heavy_t,
@@ -183,8 +405,19 @@ __global__ void __launch_bounds__(256) msm_accum_kernel(const Affine* __restrict
             HeavyChunk ch = {s + q * chunk, (s + (q + 1) * chunk < e) ? s + (q + 1) * chunk : e};
             heavy_chunks[slot + q] = ch;
         }
-    } else {
-        for (uint32_t i = s; i < e; i++) accum_signed<FqUA>(acc, bases, vals[i]);  // throughput-bound: explicit-mad multiplier
+    } else if (s < e) {
+        // The point of the next entry is fetched before the current addition starts: with a window table the points
+        // are gathers from hundreds of MB of HBM, and one addition (~2.3 k instructions) hides the whole miss.
+        uint32_t v = vals[s];
+        Affine p = bases[v & 0x7fffffffu];
+        for (uint32_t i = s + 1; i < e; i++) {
+            const uint32_t vn = vals[i];
+            const Affine pn = bases[vn & 0x7fffffffu];
+            xyzzu_add_affine<FqUA>(acc, p, (v >> 31) != 0);  // throughput-bound: explicit-mad multiplier
+            v = vn;
+            p = pn;
+        }
+        xyzzu_add_affine<FqUA>(acc, p, (v >> 31) != 0);
     }
     buckets[b] = acc;
 }
@@ -204,7 +437,7 @@ __device__ __forceinline__ XYZZu block_tree_sum(XYZZu v, XYZZu* sh) {
     return sh[0];
 }
 
-// K2h-1: workgroups stride over the chunk list; every wave exits once its index passes the count
+// B-heavy 1: workgroups stride over the chunk list; every wave exits once its index passes the count
 __global__ void __launch_bounds__(256) msm_heavy_chunk_kernel(const Affine* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                               const uint32_t* __restrict__ heavy_counts, const HeavyChunk* __restrict__ heavy_chunks,
                                                               XYZZu* __restrict__ chunk_sums) {
@@ -220,7 +453,7 @@ __global__ void __launch_bounds__(256) msm_heavy_chunk_kernel(const Affine* __re
     }
 }
 
-// K2h-2: one workgroup per over-full bucket sums its chunk sums into the bucket
+// B-heavy 2: one workgroup per over-full bucket sums its chunk sums into the bucket
 __global__ void __launch_bounds__(256) msm_heavy_final_kernel(const uint32_t* __restrict__ heavy_counts, const HeavyBucket* __restrict__ heavy_buckets,
                                                               const XYZZu* __restrict__ chunk_sums, XYZZu* __restrict__ buckets) {
     __shared__ XYZZu sh[256];
@@ -235,105 +468,110 @@ __global__ void __launch_bounds__(256) msm_heavy_final_kernel(const uint32_t* __
     }
 }
 
-// K3: summation by parts (arithmetic.rs:95-99), restated so that no lane runs a long chain of dependent
-// EC additions (one XYZZ add is ~3.5 k instructions = ~6 us for a lone wave):
-//   R1  lane t of window w folds s1 = 2^log_s1 consecutive buckets by running sums:
-//         RUN[t] = sum B_i,  ACC[t] = sum (i - t*s1 + 1) B_i         (chain 2*s1)
-//       window sum = sum_t ACC[t] + s1 * sum_t t * RUN[t]
-//   R2  the weighted sum over t is taken digit by digit in radix 32: t = sum_d t_d 32^d, so
-//         sum_t t*RUN[t] = sum_d 32^d sum_v v * T[d][v],   T[d][v] = sum_{t : t_d = v} RUN[t]
-//       one workgroup per (window, d, v) forms T[d][v] (plain sum: per-lane partial + LDS tree); slot d = D
-//       holds 32 partial plain sums of ACC.
-//   R3  one workgroup per window: v*T[d][v] by double-and-add, tree over v, Horner over d, times s1, plus ACC.
-__global__ void __launch_bounds__(256) msm_reduce1_kernel(const XYZZu* __restrict__ buckets, uint32_t n_seg_total, uint32_t log_s1,
-                                                          XYZZu* __restrict__ acc_out, XYZZu* __restrict__ run_out) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_seg_total) return;
-    const uint32_t s1 = 1u << log_s1;
-    const XYZZu* seg = buckets + ((size_t)t << log_s1);
-    XYZZu run = xyzzu_identity(), acc = xyzzu_identity();
-    for (uint32_t i = s1; i-- > 0;) {
-        xyzzu_add(run, seg[i]);
-        xyzzu_add(acc, run);
-    }
-    acc_out[t] = acc;
-    run_out[t] = run;
-}
-
-struct DigitPlan {
-    uint32_t D;          // number of digits of the segment index t (<= 7)
-    uint32_t width[8];   // bits of digit d (<= 5), split as evenly as possible so every T[d][v] sums equally many terms
-    uint32_t shift[8];   // bit position of digit d
+// C: summation by parts (arithmetic.rs:95-99) as plain sums.  For an array X of rows x cols elements (cols = 2^t)
+// with weights (i + o) << k on element i = h * cols + l:
+//     sum_i ((i + o) << k) X_i = sum_h (h << (k + t)) R_h + sum_l ((l + o) << k) C_l,   R_h = sum_l X, C_l = sum_h X
+// so a weighted sum over N elements becomes two over sqrt(N) after one pass of N-term plain sums (2 additions per
+// element, every one of them independent of the others -- no lane runs a long chain).  The buckets of a set carry
+// (o, k) = (1, 0); two such passes leave at most four arrays of <= 64 elements per set, which msm_final_kernel finishes.
+struct RowColJob {
+    const XYZZu* in;
+    XYZZu* out;           // row sums [n_arr][rows] or column sums [n_arr][cols]
+    uint32_t n_arr, log_rows, log_cols;
+    uint32_t cols_kind;   // 0: this job forms the row sums, 1: the column sums
+    uint32_t g_log;       // 2^g_log lanes share one sum
+    uint32_t first_block; // this job's first workgroup
+};
+struct RowColArgs {
+    RowColJob job[4];
+    uint32_t n_jobs;
 };
 
-// T laid out [w][d][v]; LPT lanes of a single-wave workgroup form one T.  One wave64 already saturates its SIMD's issue
-// rate (a lone wave's EC add takes 6.5 us = 3.5 k instructions at ~4 cycles), and a wave pays full price for a tree level
-// however few of its lanes are active, so what counts is waves x chain length against the 1024 SIMDs:
-//   LPT = 32, two T's per wave: a lone MSM (2 048 T's -> one wave per SIMD, chain = sums/32 + 5 tree levels; measured 170 -> 158 us
-//   at 2^20 and 167 -> 120 us at 2^17 against one T per wave);
-//   LPT = 16, four T's per wave: fused batches, tens of thousands of T's, throughput-bound (a third of the wave-additions of LPT = 64).
-template <int LPT>
-__global__ void __launch_bounds__(64) msm_reduce2_kernel(const XYZZu* __restrict__ acc_in, const XYZZu* __restrict__ run_in, uint32_t m1,
-                                                         DigitPlan dp, uint32_t n_T, XYZZu* __restrict__ T) {
-    __shared__ XYZZu sh[64];
-    const uint32_t D = dp.D;
-    const uint32_t sub = threadIdx.x % LPT;
-    const uint32_t ti = blockIdx.x * (64 / LPT) + threadIdx.x / LPT;  // which T this lane works for
-    const bool live = ti < n_T;
-    const uint32_t v = ti & 31;
-    const uint32_t d = (ti >> 5) % (D + 1);
-    const uint32_t w = (ti >> 5) / (D + 1);
+__global__ void __launch_bounds__(256) msm_rowcol_kernel(RowColArgs args) {
+    __shared__ XYZZu sh[256];
+    uint32_t ji = 0;
+    for (uint32_t q = 1; q < args.n_jobs; q++)
+        if (blockIdx.x >= args.job[q].first_block) ji = q;
+    const RowColJob& J = args.job[ji];
+    const uint32_t G = 1u << J.g_log, g = threadIdx.x & (G - 1);
+    const uint32_t rows = 1u << J.log_rows, cols = 1u << J.log_cols;
+    const uint32_t per_arr = J.cols_kind ? cols : rows;
+    const uint32_t task = (blockIdx.x - J.first_block) * (256u >> J.g_log) + (threadIdx.x >> J.g_log);
+    const bool live = task < J.n_arr * per_arr;
     XYZZu acc = xyzzu_identity();
-    if (!live) {
-    } else if (d == D) {
-        // plain sum of ACC[t] over t == v (mod 32)
-        const XYZZu* A = acc_in + (size_t)w * m1;
-        for (uint32_t t = v + 32 * sub; t < m1; t += 32 * LPT) xyzzu_add(acc, A[t]);
-    } else if (v < (1u << dp.width[d])) {
-        // RUN[t] over the t whose digit d is v: t = hi << (shift + width) | v << shift | lo
-        const XYZZu* Rn = run_in + (size_t)w * m1;
-        const uint32_t sh_d = dp.shift[d], wd = dp.width[d];
-        const uint32_t n_sel = (((m1 - 1) >> (sh_d + wd)) + 1) << sh_d;  // (hi, lo) combinations that can land below m1
-        for (uint32_t q = sub; q < n_sel; q += LPT) {
-            uint32_t lo = q & ((1u << sh_d) - 1), hi = q >> sh_d;
-            uint32_t t = (hi << (sh_d + wd)) | (v << sh_d) | lo;
-            if (t < m1) xyzzu_add(acc, Rn[t]);
+    if (live) {
+        const uint32_t a = task / per_arr, idx = task - a * per_arr;
+        const XYZZu* X = J.in + ((size_t)a << (J.log_rows + J.log_cols));
+        if (!J.cols_kind) {
+            const XYZZu* row = X + ((size_t)idx << J.log_cols);
+            for (uint32_t l = g; l < cols; l += G) xyzzu_add(acc, row[l]);
+        } else {
+            for (uint32_t h = g; h < rows; h += G) xyzzu_add(acc, X[((size_t)h << J.log_cols) + idx]);
         }
     }
-    // tree over the LPT lanes of each group
     sh[threadIdx.x] = acc;
     __syncthreads();
-    for (uint32_t stride = LPT >> 1; stride >= 1; stride >>= 1) {
-        if (sub < stride) {
-            XYZZu a = sh[threadIdx.x];
-            xyzzu_add(a, sh[threadIdx.x + stride]);
-            sh[threadIdx.x] = a;
+    for (uint32_t stride = G >> 1; stride >= 1; stride >>= 1) {
+        if (g < stride) {
+            XYZZu x = sh[threadIdx.x];
+            xyzzu_add(x, sh[threadIdx.x + stride]);
+            sh[threadIdx.x] = x;
         }
         __syncthreads();
     }
-    if (sub == 0 && live) T[ti] = sh[threadIdx.x];
+    if (live && g == 0) J.out[task] = sh[threadIdx.x];
 }
 
-// one workgroup of 256 per window: lane (d, v) scales T[d][v] by v << shift[d] (double-and-add), one tree over
-// all lanes sums them together with the ACC partial sums, then times s1
-__global__ void __launch_bounds__(256) msm_reduce3_kernel(const XYZZu* __restrict__ T, DigitPlan dp, uint32_t log_s1,
-                                                          XYZZ* __restrict__ window_sums) {
+struct FinalArr {
+    const XYZZu* base;  // array of set 0
+    uint32_t stride;    // elements between consecutive sets
+    uint32_t len;       // <= 64
+    uint32_t o, k;      // weight of element v: (v + o) << k
+    uint32_t nbits;     // bits of the largest weight
+};
+struct FinalArgs {
+    FinalArr arr[4];
+    uint32_t n_arr;
+};
+
+// one workgroup of 256 per bucket set: lane (array, v) scales its element (double-and-add), one tree sums everything
+__global__ void __launch_bounds__(256) msm_final_kernel(FinalArgs args, XYZZ* __restrict__ set_sums) {
     __shared__ XYZZu sh[256];
-    const uint32_t D = dp.D;
-    const uint32_t w = blockIdx.x;
-    const XYZZu* Tw = T + (size_t)w * (D + 1) * 32;
-    const uint32_t d = threadIdx.x >> 5, v = threadIdx.x & 31;  // D + 1 <= 8 slots of 32 lanes
+    const uint32_t set = blockIdx.x, ai = threadIdx.x >> 6, v = threadIdx.x & 63;
     XYZZu x = xyzzu_identity();
-    if (d < D) {
-        if (v != 0 && v < (1u << dp.width[d])) x = xyzzu_mul_small(Tw[d * 32 + v], (v << dp.shift[d]) << log_s1, dp.shift[d] + dp.width[d] + log_s1);
-    } else if (d == D) {
-        x = Tw[D * 32 + v];
+    if (ai < args.n_arr) {
+        const FinalArr& A = args.arr[ai];
+        if (v < A.len) {
+            const uint32_t wgt = (v + A.o) << A.k;
+            if (wgt) x = xyzzu_mul_small(A.base[(size_t)set * A.stride + v], wgt, A.nbits);
+        }
     }
     XYZZu r = block_tree_sum(x, sh);
-    if (threadIdx.x == 0) window_sums[w] = xyzzu_to_ext(r);  // canonical E-form for the host Horner
+    if (threadIdx.x == 0) set_sums[set] = xyzzu_to_ext(r);  // canonical E-form
+}
+
+// Fixed-base table, one step: out[i] = 2^c * prev[i] (XYZZ; normalised to affine by ec_normalize afterwards)
+__global__ void __launch_bounds__(256) msm_table_step_kernel(const Affine* __restrict__ prev, XYZZ* __restrict__ out, uint32_t n, uint32_t c) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Affine p = prev[i];
+    if (affine_is_identity(p)) {
+        out[i] = xyzz_identity();
+        return;
+    }
+    XYZZu q = xyzzu_double_affine<FqUA>(fu_from_ext(p.x), fu_from_ext(p.y));
+    for (uint32_t k = 1; k < c; k++) q = xyzzu_double(q);
+    out[i] = xyzzu_to_ext(q);
 }
 
 static uint32_t g_window_override = 0;
+static size_t g_heavy_div = 32768;
+static size_t g_bin_entries = 8192;
+static uint32_t g_accum_bs = 256;
+static bool g_global_order = true;
+void msm_set_l1_mode(int m) { g_global_order = m == 0; }
+void msm_set_bin_entries(size_t d) { g_bin_entries = d ? d : 8192; }
+void msm_set_heavy_div(size_t d) { g_heavy_div = d ? d : 32768; }
 static size_t g_max_chunk = (size_t)1 << 26;
 void msm_set_max_chunk(size_t m) { g_max_chunk = m ? m : ((size_t)1 << 26); }
 static uint32_t g_reserved_cus = 0;  // measured on MI355X: every partition (16..96 CUs) was slower than none
@@ -341,48 +579,77 @@ void msm_set_reserved_cus(uint32_t k) { g_reserved_cus = k; }
 uint32_t msm_get_reserved_cus() { return g_reserved_cus; }
 void msm_set_window(uint32_t c) { g_window_override = c; }
 
-static MsmPlan make_plan(size_t n, bool fused = false) {
-    MsmPlan p;
-    uint32_t c;
-    if (g_window_override) {
-        c = g_window_override;
-    } else {
-        uint32_t lg = 0;
-        while (((size_t)1 << (lg + 1)) <= n) lg++;
-        // enough buckets to fill 256 CUs, few enough that the reduction stays small, and 254 mod c large so
-        // that the top window is not a handful of over-full buckets
-        // a fused batch has count times the buckets for the same chain lengths: narrower windows pay (measured per MSM,
-        // 16 x 2^17: c = 13 0.42 ms, c = 15 0.47 ms; 16 x 2^13: c = 10 0.156, c = 13 0.183)
-        if (fused && lg >= 13 && lg <= 18) c = lg <= 13 ? 10 : lg <= 16 ? 12 : lg == 17 ? 13 : 14;
-        else if (lg <= 8) c = 7;
-        else if (lg <= 12) c = 10;
-        else if (lg <= 15) c = 13;
-        else if (lg <= 18) c = 15;
-        else c = 16;  // re-swept after the sort went to two passes: 2^16 0.79 (c = 15) vs 0.83 ms (13); 2^19 1.43 (16) vs 1.53 ms (15)
-    }
+static uint32_t floor_log2(size_t n) {
+    uint32_t lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) lg++;
+    return lg;
+}
+
+// window width of the plain form
+static uint32_t plain_window(size_t n, bool fused) {
+    if (g_window_override) return g_window_override;
+    const uint32_t lg = floor_log2(n);
+    // enough buckets to fill 256 CUs, few enough that the reduction stays small, and 254 mod c large so
+    // that the top window is not a handful of over-full buckets
+    // a fused batch has count times the buckets for the same chain lengths: narrower windows pay
+    if (fused && lg >= 13 && lg <= 18) return lg <= 13 ? 10 : lg <= 16 ? 12 : lg == 17 ? 13 : 14;
+    if (lg <= 8) return 7;
+    if (lg <= 12) return 10;
+    if (lg <= 15) return 13;
+    if (lg <= 18) return 15;
+    return 16;
+}
+
+// window width a fixed-base table is built with for n pinned points: all windows share one bucket set, so the
+// reduction costs 2 * 2^(c-1) additions once instead of per window and c follows n
+static uint32_t normalise_window(uint32_t c) {
     if (c < 2) c = 2;
-    if (c > 22) c = 22;
+    if (c > 24) c = 24;
+    const uint32_t W = (255 + c - 1) / c;
+    return (255 + W - 1) / W;
+}
+
+uint32_t msm_table_window(size_t n) {
+    if (g_window_override) return normalise_window(g_window_override);
+    const uint32_t lg = floor_log2(n);
+    uint32_t c;
+    if (lg <= 10) c = lg < 4 ? 4 : lg;
+    else if (lg <= 19) c = lg;
+    else if (lg <= 22) c = 20;
+    else c = 22;
+    return normalise_window(c);
+}
+
+static MsmPlan make_plan(size_t n, bool fused, const MsmTable* tab) {
+    MsmPlan p;
+    uint32_t c = tab ? tab->c : plain_window(n, fused);
+    if (c < 2) c = 2;
+    if (c > 24) c = 24;
+    p.W = (255 + c - 1) / c;
+    c = (255 + p.W - 1) / p.W;  // the smallest width that gives W windows (18 -> 17, 21 -> 20, 23 -> 22)
     p.c = c;
-    p.W = 254 / c + 1;
+    p.q = 255 - p.W * (c - 1);
+    p.cb = c - 1;
     p.NB = 1u << (c - 1);
-    p.log_s1 = (c - 1) < 3 ? (c - 1) : 3;  // short chains when there are few buckets, 8-bucket segments when many
-    // A lone lane adds ~6 us per pair, and the kernel cannot finish faster than 2 * n*W / 65536 add-times
+    p.shared = tab ? 1 : 0;
+    // A lone lane adds ~6 us per entry, and the kernel cannot finish faster than 2 * n*W / 65536 add-times
     // anyway (64 lanes x 1024 SIMDs): buckets above that go to the chunked path, or one lane's chain
     // (e.g. the few buckets of a narrow top window) sets the kernel's duration.
-    size_t t = (n * p.W) / 32768;
+    size_t t = (n * p.W) / g_heavy_div;
     if (t < 32) t = 32;
     p.heavy_t = (uint32_t)t;
     p.chunk = 4096;
     return p;
 }
 
-uint32_t msm_get_window(size_t n) { return make_plan(n).c; }
+uint32_t msm_get_window(size_t n) { return make_plan(n, false, nullptr).c; }
 
-// host Horner over window sums (arithmetic.rs:46-49): acc = sum_w 2^(c*w) * S_w
+// host Horner over the set sums of one MSM in the plain form (arithmetic.rs:46-49): acc = sum_w 2^(pos_w) * S_w
 static XYZZ combine_windows(const XYZZ* ws, const MsmPlan& p) {
     h64::P acc = h64::identity();
     for (uint32_t w = p.W; w-- > 0;) {
-        for (uint32_t k = 0; k < p.c; k++) acc = h64::pdouble(acc);
+        const uint32_t width = w < p.q ? p.c : p.c - 1;  // window w + 1 starts `width` bits above window w
+        for (uint32_t k = 0; k < width; k++) acc = h64::pdouble(acc);
         h64::padd(acc, h64::from_xyzz(ws[w]));
     }
     return h64::to_xyzz(acc);
@@ -390,84 +657,103 @@ static XYZZ combine_windows(const XYZZ* ws, const MsmPlan& p) {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Workspace layout of one in-flight MSM ("slot")
+static uint32_t bits_of(uint32_t v) {
+    uint32_t b = 0;
+    while (v) {
+        b++;
+        v >>= 1;
+    }
+    return b;
+}
+
+// Workspace layout of one in-flight run ("slot")
 struct MsmLayout {
-    uint32_t fuse, Wt;  // MSMs sharing this workspace as one run (1 normally) and their windows in total: fuse * p.W
+    uint32_t fuse;      // MSMs sharing this workspace as one run (1 normally)
+    uint32_t n_sets;    // bucket sets of the run: fuse (fixed-base) or fuse * W
     MsmPlan p;
-    DigitPlan dplan;
-    size_t n, E;
-    uint32_t n_buckets, m1, D, bin_shift;
-    int end_bit;
-    size_t cub_bytes, max_chunks, max_heavy;
-    size_t o_keys0, o_keys1, o_vals0, o_vals1, o_cub, o_start, o_end, o_counts, o_perm, o_hist, o_buckets, o_acc, o_run, o_wsum, o_T, o_hcnt,
-        o_hb, o_hc, o_hs, o_zero_end, o_ptrs, total;
+    size_t n, E;        // pairs per MSM; upper bound of the entries of the run
+    uint32_t K;         // buckets in total
+    uint32_t L, C1, bin_shift;
+    // reduction: levels 0..2 of row/column passes before the final kernel
+    uint32_t levels, s, rb, s2, s3;
+    size_t max_chunks, max_heavy;
+    size_t o_zero, o_zero_end, o_ccnt, o_ccur, o_hist, o_hcnt, o_cstart, o_tmp, o_vals, o_start, o_counts, o_perm, o_buckets, o_RA, o_CA, o_RR,
+        o_RC, o_CR, o_CC, o_sums, o_hb, o_hc, o_hs, o_ptrs, total;
 };
 
-static int msm_layout(size_t n, hipStream_t s, MsmLayout* L, uint32_t fuse = 1) {
-    MsmPlan p = make_plan(n, fuse > 1);
+static int msm_layout(size_t n, MsmLayout* L, uint32_t fuse, const MsmTable* tab) {
+    MsmPlan p = make_plan(n, fuse > 1, tab);
     L->p = p;
     L->n = n;
     L->fuse = fuse;
-    L->Wt = p.W * fuse;
-    L->E = n * L->Wt;
+    L->n_sets = p.shared ? fuse : fuse * p.W;
+    L->E = n * p.W * fuse;
     if (L->E >= ((size_t)1 << 31)) {
-        set_error("msm: n*W = %zu pairs exceeds the 2^31 sort limit (window override too small?)", L->E);
+        set_error("msm: %zu entries exceed the 2^31 limit of one run (window override too small?)", L->E);
         return 1;
     }
-    if (p.W > MSM_MAX_WINDOWS * 2 || L->Wt > 4096) {
-        set_error("msm: too many windows");
+    if (p.shared && (uint64_t)p.W * tab->stride >= (1ull << 31)) {
+        set_error("msm: fixed-base table index exceeds 31 bits");
         return 1;
     }
-    if ((uint64_t)L->Wt * p.NB >= (1ull << 31)) {
-        set_error("msm: too many buckets");
+    const uint64_t K64 = (uint64_t)L->n_sets << p.cb;
+    if (K64 > ((uint64_t)MSM_MAX_C1 << MSM_MAX_L)) {
+        set_error("msm: too many buckets (%llu) for one run", (unsigned long long)K64);
         return 1;
     }
-    L->n_buckets = L->Wt * p.NB;
-    L->m1 = p.NB >> p.log_s1;
-    // Only the slot bits are sorted.  The pairs leave the digits kernel window-major and the radix sort is stable, so after
-    // sorting on the low c bits the entries of one (window, slot) bucket are still one contiguous run (ordered by slot, then
-    // window, then pair index) -- which is all the bounds kernel and the accumulate kernel need.  That is 2 radix passes for
-    // c <= 16 instead of the 3 a sort on (window, slot) takes.  One sort of all n*W pairs at every size (one sort per window,
-    // the earlier choice above 2^22 pairs, measured slower: 8.1 vs 7.5 ms at 2^22, 27.9 vs 27.1 ms at 2^24).
-    L->end_bit = (int)p.c;
-    L->cub_bytes = 0;
-    H2_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, L->cub_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                                (uint32_t*)nullptr, (int)L->E, 0, L->end_bit, s));
+    L->K = (uint32_t)K64;
+    // level-1 coarse bins: about one level-2 tile (MSM_STAGE entries) each, at most MSM_MAX_C1 of them (so that the
+    // runs a level-1 workgroup writes stay long), at most 2^MSM_MAX_L buckets each, never straddling two sets
+    uint32_t want = 1;
+    while (want < MSM_MAX_C1 && (size_t)want * g_bin_entries < L->E) want <<= 1;
+    uint32_t Lb = 0;
+    while (Lb < p.cb && Lb < MSM_MAX_L && (K64 >> Lb) > want) Lb++;
+    while ((K64 >> Lb) > MSM_MAX_C1) {
+        if (Lb >= p.cb || Lb >= MSM_MAX_L) {
+            set_error("msm: too many bucket sets (%u) for one run", L->n_sets);
+            return 1;
+        }
+        Lb++;
+    }
+    L->L = Lb;
+    L->C1 = (uint32_t)(K64 >> Lb);
+    // size classes: width 2^bin_shift entries, the mean bucket size lands in classes 50..100 (of 256)
+    L->bin_shift = 0;
+    const size_t mean_bucket = (p.shared ? n * p.W : n) >> p.cb;
+    while ((mean_bucket >> L->bin_shift) > 100) L->bin_shift++;
     L->max_chunks = L->E / p.chunk + L->E / p.heavy_t + 16;  // sum of ceil(cnt/chunk) over buckets with cnt > heavy_t
     L->max_heavy = L->E / p.heavy_t + 16;
-    // digits of the segment index t < m1: ceil(bits / 5) digits of near-equal width
-    uint32_t tbits = 0;
-    while ((1u << tbits) < L->m1) tbits++;
-    memset(&L->dplan, 0, sizeof(L->dplan));
-    L->D = tbits ? (tbits + 4) / 5 : 1;
-    L->dplan.D = L->D;
-    for (uint32_t d = 0, pos = 0; d < L->D; d++) {
-        uint32_t wd = tbits / L->D + (d < tbits % L->D ? 1 : 0);
-        L->dplan.width[d] = wd;
-        L->dplan.shift[d] = pos;
-        pos += wd;
-    }
-    // size classes: width 2^bin_shift pairs, the mean bucket size lands in classes 50..100 (of 256)
-    L->bin_shift = 0;
-    while (((n / p.NB) >> L->bin_shift) > 100) L->bin_shift++;
+    // reduction geometry
+    const uint32_t cb = p.cb;
+    L->levels = cb <= 6 ? 0 : cb <= 12 ? 1 : 2;
+    L->s = L->levels ? (cb + 1) / 2 : 0;  // level A: cols = 2^s, rows = 2^rb
+    L->rb = cb - L->s;
+    L->s2 = L->levels == 2 ? (L->rb + 1) / 2 : 0;  // level B on the row sums: cols = 2^s2
+    L->s3 = L->levels == 2 ? (L->s + 1) / 2 : 0;   // level B on the column sums: cols = 2^s3
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t E = L->E;
-    const uint32_t nb = L->n_buckets;
-    L->o_keys0 = carve(E * 4); L->o_keys1 = carve(E * 4); L->o_vals0 = carve(E * 4); L->o_vals1 = carve(E * 4);
-    L->o_cub = carve(L->cub_bytes);
-    L->o_start = carve(((size_t)nb + 2) * 4);
-    L->o_end = carve(((size_t)nb + 2) * 4);
+    const uint32_t K = L->K, ns = L->n_sets;
+    L->o_zero = off;  // one memset clears: coarse counts, coarse cursors, heavy counters
+    L->o_ccnt = carve((size_t)MSM_MAX_C1 * 4);
+    L->o_ccur = carve((size_t)MSM_MAX_C1 * 4);
     L->o_hist = carve(512 * 4);
     L->o_hcnt = carve(16);
-    L->o_zero_end = off;  // start[], end[], hist[], heavy counters are contiguous: one memset clears them all
-    L->o_counts = carve((size_t)nb * 4);
-    L->o_perm = carve((size_t)nb * 4);
-    L->o_buckets = carve((size_t)nb * sizeof(XYZZu));
-    L->o_acc = carve((size_t)L->Wt * L->m1 * sizeof(XYZZu));
-    L->o_run = carve((size_t)L->Wt * L->m1 * sizeof(XYZZu));
-    L->o_wsum = carve((size_t)L->Wt * sizeof(XYZZ));
-    L->o_T = carve((size_t)L->Wt * (L->D + 1) * 32 * sizeof(XYZZu));
+    L->o_zero_end = off;
+    L->o_cstart = carve(((size_t)MSM_MAX_C1 + 1) * 4);
+    L->o_tmp = carve(E * 8);
+    L->o_vals = carve(E * 4);
+    L->o_start = carve((size_t)K * 4);
+    L->o_counts = carve((size_t)K * 4);
+    L->o_perm = carve((size_t)K * 4);
+    L->o_buckets = carve((size_t)K * sizeof(XYZZu));
+    L->o_RA = carve(((size_t)ns << L->rb) * sizeof(XYZZu));
+    L->o_CA = carve(((size_t)ns << L->s) * sizeof(XYZZu));
+    L->o_RR = carve(((size_t)ns << (L->rb - L->s2)) * sizeof(XYZZu));
+    L->o_RC = carve(((size_t)ns << L->s2) * sizeof(XYZZu));
+    L->o_CR = carve(((size_t)ns << (L->s - L->s3)) * sizeof(XYZZu));
+    L->o_CC = carve(((size_t)ns << L->s3) * sizeof(XYZZu));
+    L->o_sums = carve((size_t)ns * sizeof(XYZZ));
     L->o_hb = carve(L->max_heavy * sizeof(HeavyBucket));
     L->o_hc = carve(L->max_chunks * sizeof(HeavyChunk));
     L->o_hs = carve(L->max_chunks * sizeof(XYZZu));
@@ -476,45 +762,62 @@ static int msm_layout(size_t n, hipStream_t s, MsmLayout* L, uint32_t fuse = 1) 
     return 0;
 }
 
-// stage A (memory-bound): digits, radix sort, bucket bounds, size order
-static int msm_stage_a(Ctx* c, const MsmLayout& L, char* base, const Fe* const* d_scalars_list, hipStream_t s) {
+// stage A (memory-bound): digits, two-level counting sort by bucket, size order
+static int msm_stage_a(Ctx* c, const MsmLayout& L, char* base, const Fe* const* d_scalars_list, const MsmTable* tab, hipStream_t s) {
     const MsmPlan& p = L.p;
     const size_t n = L.n;
-    uint32_t *keys0 = (uint32_t*)(base + L.o_keys0), *keys1 = (uint32_t*)(base + L.o_keys1);
-    uint32_t *vals0 = (uint32_t*)(base + L.o_vals0), *vals1 = (uint32_t*)(base + L.o_vals1);
-    uint32_t *start = (uint32_t*)(base + L.o_start), *endp = (uint32_t*)(base + L.o_end);
-    uint32_t *counts = (uint32_t*)(base + L.o_counts), *perm = (uint32_t*)(base + L.o_perm), *hist = (uint32_t*)(base + L.o_hist);
+    uint32_t *ccnt = (uint32_t*)(base + L.o_ccnt), *ccur = (uint32_t*)(base + L.o_ccur), *cstart = (uint32_t*)(base + L.o_cstart);
+    uint32_t *vals = (uint32_t*)(base + L.o_vals), *start = (uint32_t*)(base + L.o_start);
+    uint32_t *counts = (uint32_t*)(base + L.o_counts), *perm = (uint32_t*)(base + L.o_perm);
     int t0 = c->timer_begin("msm_digits", s);
-    H2_CHECK(hipMemsetAsync(start, 0, L.o_zero_end - L.o_start, s));  // start[], end[], hist[], heavy counters
-    const Fe* const* d_list = nullptr;
-    if (L.fuse > 1) {  // the scalar arrays' addresses, read by the kernel per blockIdx.y
-        H2_CHECK(hipMemcpyAsync(base + L.o_ptrs, d_scalars_list, L.fuse * sizeof(void*), hipMemcpyHostToDevice, s));  // pageable: staged before return
-        d_list = (const Fe* const*)(base + L.o_ptrs);
+    H2_CHECK(hipMemsetAsync(base + L.o_zero, 0, L.o_zero_end - L.o_zero, s));
+    L1Args a;
+    a.scalars_one = d_scalars_list[0];
+    a.list = nullptr;
+    if (L.fuse > 1) {  // the scalar arrays' addresses, read by the kernels per blockIdx.y (staged through pinned memory)
+        int rc = c->stage_h2d(base + L.o_ptrs, d_scalars_list, L.fuse * sizeof(void*), s);
+        if (rc) return rc;
+        a.list = (const Fe* const*)(base + L.o_ptrs);
     }
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256), L.fuse), dim3(256), 0, s, d_scalars_list[0], d_list, (uint32_t)n, p.c, p.W, p.NB,
-                       keys0, vals0);
+    a.n = (uint32_t)n;
+    a.c = p.c;
+    a.q = p.q;
+    a.W = p.W;
+    a.cb = p.cb;
+    a.L = L.L;
+    a.C1 = L.C1;
+    a.shared = p.shared;
+    a.stride = tab ? (uint32_t)tab->stride : 0;
+    a.tile = (MSM_STAGE / p.W) & ~63u;  // scalars per scatter workgroup: tile * W entries fit the LDS stage
+    if (a.tile > 1024) a.tile = 1024;
+    a.g_cnt = ccnt;
+    a.coarse_start = cstart;
+    a.g_cursor = ccur;
+    a.tmp = (uint2*)(base + L.o_tmp);
+    hipLaunchKernelGGL(msm_l1_count_kernel, dim3((uint32_t)((n + MSM_COUNT_TILE - 1) / MSM_COUNT_TILE), L.fuse), dim3(256), 0, s, a);
     H2_CHECK(hipGetLastError());
     c->timer_end(t0, s);
     int t1 = c->timer_begin("msm_sort", s);
-    H2_CHECK(hipcub::DeviceRadixSort::SortPairs(base + L.o_cub, const_cast<size_t&>(L.cub_bytes), keys0, keys1, vals0, vals1, (int)L.E, 0, L.end_bit, s));
-    {
-        size_t blocks = (L.E + 255) / 256;
-        uint32_t grid = (uint32_t)(blocks < (size_t)c->sm_count * 16 ? blocks : (size_t)c->sm_count * 16);
-        hipLaunchKernelGGL(msm_bounds_kernel, dim3(grid), dim3(256), 0, s, keys1, (size_t)0, L.E, p.c, start, endp);
+    hipLaunchKernelGGL(msm_l1_scan_kernel, dim3(1), dim3(1024), 0, s, ccnt, L.C1, cstart);
+    H2_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(msm_l1_scatter_kernel, dim3((uint32_t)((n + a.tile - 1) / a.tile), L.fuse), dim3(1024), 0, s, a);
+    H2_CHECK(hipGetLastError());
+    uint32_t* hist = (uint32_t*)(base + L.o_hist);
+    hipLaunchKernelGGL(msm_l2_kernel, dim3(L.C1), dim3(1024), 0, s, (const uint2*)(base + L.o_tmp), cstart, L.L, L.bin_shift, vals, start, counts, perm,
+                       g_global_order ? hist : (uint32_t*)nullptr);
+    H2_CHECK(hipGetLastError());
+    if (g_global_order) {
+        hipLaunchKernelGGL(msm_bucket_scatter_kernel, dim3((L.K + 255) / 256), dim3(256), 0, s, counts, L.K, L.bin_shift, hist, perm);
         H2_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(msm_bucket_hist_kernel, dim3((L.n_buckets + 255) / 256), dim3(256), 0, s, start, endp, 0u, L.n_buckets, L.bin_shift, counts, hist);
-    H2_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(msm_bucket_scatter_kernel, dim3((L.n_buckets + 255) / 256), dim3(256), 0, s, counts, 0u, L.n_buckets, L.bin_shift, hist, perm);
-    H2_CHECK(hipGetLastError());
     c->timer_end(t1, s);
     return 0;
 }
 
 // stage B (VALU-bound): bucket accumulation, plus the chunked path for over-full buckets
-static int msm_stage_b(Ctx* c, const MsmLayout& L, char* base, const Affine* d_bases, hipStream_t s) {
+static int msm_stage_b(Ctx* c, const MsmLayout& L, char* base, const Affine* d_points, hipStream_t s) {
     const MsmPlan& p = L.p;
-    uint32_t* vals1 = (uint32_t*)(base + L.o_vals1);
+    uint32_t* vals = (uint32_t*)(base + L.o_vals);
     uint32_t *start = (uint32_t*)(base + L.o_start), *counts = (uint32_t*)(base + L.o_counts), *perm = (uint32_t*)(base + L.o_perm);
     XYZZu* buckets = (XYZZu*)(base + L.o_buckets);
     uint32_t* hcnt = (uint32_t*)(base + L.o_hcnt);
@@ -522,13 +825,13 @@ static int msm_stage_b(Ctx* c, const MsmLayout& L, char* base, const Affine* d_b
     HeavyChunk* hc = (HeavyChunk*)(base + L.o_hc);
     XYZZu* hs = (XYZZu*)(base + L.o_hs);
     int t2 = c->timer_begin("msm_accum", s);
-    hipLaunchKernelGGL(msm_accum_kernel, dim3((L.n_buckets + 255) / 256), dim3(256), 0, s, d_bases, vals1, start, counts, perm,
-                       L.n_buckets, p.heavy_t, p.chunk, buckets, hcnt, hb, hc);
+    hipLaunchKernelGGL(msm_accum_kernel, dim3((L.K + g_accum_bs - 1) / g_accum_bs), dim3(g_accum_bs), 0, s, d_points, vals, start, counts, perm, L.K,
+                       p.heavy_t, p.chunk, buckets, hcnt, hb, hc);
     H2_CHECK(hipGetLastError());
     c->timer_end(t2, s);
     int t3 = c->timer_begin("msm_heavy", s);
     uint32_t hgrid = (uint32_t)(L.max_chunks < (size_t)c->sm_count * 4 ? L.max_chunks : (size_t)c->sm_count * 4);
-    hipLaunchKernelGGL(msm_heavy_chunk_kernel, dim3(hgrid), dim3(256), 0, s, d_bases, vals1, hcnt, hc, hs);
+    hipLaunchKernelGGL(msm_heavy_chunk_kernel, dim3(hgrid), dim3(256), 0, s, d_points, vals, hcnt, hc, hs);
     H2_CHECK(hipGetLastError());
     uint32_t fgrid = (uint32_t)(L.max_heavy < (size_t)c->sm_count ? L.max_heavy : (size_t)c->sm_count);
     hipLaunchKernelGGL(msm_heavy_final_kernel, dim3(fgrid), dim3(256), 0, s, hcnt, hb, hs, buckets);
@@ -537,44 +840,103 @@ static int msm_stage_b(Ctx* c, const MsmLayout& L, char* base, const Affine* d_b
     return 0;
 }
 
-// stage C (latency-bound): bucket reduction to W window sums, copied to h_ws (host)
-static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_ws, hipStream_t s) {
-    const MsmPlan& p = L.p;
-    XYZZu* buckets = (XYZZu*)(base + L.o_buckets);
-    XYZZu *accs = (XYZZu*)(base + L.o_acc), *runs = (XYZZu*)(base + L.o_run), *Tsum = (XYZZu*)(base + L.o_T);
-    XYZZ* wsum = (XYZZ*)(base + L.o_wsum);
-    int t4 = c->timer_begin("msm_reduce", s);
-    uint32_t n_seg = L.Wt * L.m1;
-    hipLaunchKernelGGL(msm_reduce1_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, s, buckets, n_seg, p.log_s1, accs, runs);
-    H2_CHECK(hipGetLastError());
-    {
-        const uint32_t n_T = L.Wt * (L.D + 1) * 32;
-        if (L.fuse > 1)
-            hipLaunchKernelGGL(msm_reduce2_kernel<16>, dim3((n_T + 3) / 4), dim3(64), 0, s, accs, runs, L.m1, L.dplan, n_T, Tsum);
-        else
-            hipLaunchKernelGGL(msm_reduce2_kernel<32>, dim3((n_T + 1) / 2), dim3(64), 0, s, accs, runs, L.m1, L.dplan, n_T, Tsum);
+// the two jobs (row sums, column sums) of one row/column pass over n_arr arrays of 2^log_rows x 2^log_cols elements.
+// Lanes per sum: every lane gets the same number of terms t, with t the smallest power of two that keeps the pass
+// within one wave per SIMD (a lone wave already saturates its SIMD's issue rate, so a second one only queues).
+static void rowcol_jobs(RowColArgs* ra, const XYZZu* in, XYZZu* out_rows, XYZZu* out_cols, uint32_t n_arr, uint32_t log_rows, uint32_t log_cols,
+                        uint32_t* n_blocks) {
+    const uint64_t elems = (uint64_t)n_arr << (log_rows + log_cols);
+    uint32_t t_log = 1;
+    while ((2 * elems) >> t_log > 65536) t_log++;
+    for (uint32_t kind = 0; kind < 2; kind++) {
+        RowColJob* j = &ra->job[ra->n_jobs++];
+        const uint32_t log_terms = kind ? log_rows : log_cols, log_sums = kind ? log_cols : log_rows;
+        uint32_t g_log = log_terms > t_log ? log_terms - t_log : 0;
+        if (g_log > 8) g_log = 8;
+        j->in = in;
+        j->out = kind ? out_cols : out_rows;
+        j->n_arr = n_arr;
+        j->log_rows = log_rows;
+        j->log_cols = log_cols;
+        j->cols_kind = kind;
+        j->g_log = g_log;
+        j->first_block = *n_blocks;
+        const uint64_t tasks = (uint64_t)n_arr << log_sums;
+        const uint32_t per_block = 256u >> g_log;
+        *n_blocks += (uint32_t)((tasks + per_block - 1) / per_block);
     }
-    H2_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(msm_reduce3_kernel, dim3(L.Wt), dim3(256), 0, s, Tsum, L.dplan, p.log_s1, wsum);
+}
+
+// stage C (latency-bound): bucket reduction to one sum per set, copied to h_sums (host)
+static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_sums, hipStream_t s) {
+    XYZZu* buckets = (XYZZu*)(base + L.o_buckets);
+    XYZZu *RA = (XYZZu*)(base + L.o_RA), *CA = (XYZZu*)(base + L.o_CA), *RR = (XYZZu*)(base + L.o_RR), *RC = (XYZZu*)(base + L.o_RC);
+    XYZZu *CR = (XYZZu*)(base + L.o_CR), *CC = (XYZZu*)(base + L.o_CC);
+    XYZZ* sums = (XYZZ*)(base + L.o_sums);
+    const uint32_t ns = L.n_sets, cb = L.p.cb;
+    int t4 = c->timer_begin("msm_reduce", s);
+    FinalArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    auto set_arr = [&](uint32_t i, const XYZZu* b, uint32_t log_len, uint32_t o, uint32_t k) {
+        fa.arr[i].base = b;
+        fa.arr[i].stride = 1u << log_len;
+        fa.arr[i].len = 1u << log_len;
+        fa.arr[i].o = o;
+        fa.arr[i].k = k;
+        fa.arr[i].nbits = bits_of(((1u << log_len) - 1 + o) << k);
+    };
+    if (L.levels == 0) {
+        set_arr(0, buckets, cb, 1, 0);
+        fa.n_arr = 1;
+    } else {
+        RowColArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        uint32_t nblk = 0;
+        rowcol_jobs(&ra, buckets, RA, CA, ns, L.rb, L.s, &nblk);
+        hipLaunchKernelGGL(msm_rowcol_kernel, dim3(nblk), dim3(256), 0, s, ra);
+        H2_CHECK(hipGetLastError());
+        if (L.levels == 1) {
+            set_arr(0, RA, L.rb, 0, L.s);
+            set_arr(1, CA, L.s, 1, 0);
+            fa.n_arr = 2;
+        } else {
+            memset(&ra, 0, sizeof(ra));
+            nblk = 0;
+            rowcol_jobs(&ra, RA, RR, RC, ns, L.rb - L.s2, L.s2, &nblk);
+            rowcol_jobs(&ra, CA, CR, CC, ns, L.s - L.s3, L.s3, &nblk);
+            hipLaunchKernelGGL(msm_rowcol_kernel, dim3(nblk), dim3(256), 0, s, ra);
+            H2_CHECK(hipGetLastError());
+            set_arr(0, RR, L.rb - L.s2, 0, L.s + L.s2);
+            set_arr(1, RC, L.s2, 0, L.s);
+            set_arr(2, CR, L.s - L.s3, 0, L.s3);
+            set_arr(3, CC, L.s3, 1, 0);
+            fa.n_arr = 4;
+        }
+    }
+    hipLaunchKernelGGL(msm_final_kernel, dim3(ns), dim3(256), 0, s, fa, sums);
     H2_CHECK(hipGetLastError());
     c->timer_end(t4, s);
-    H2_CHECK(hipMemcpyAsync(h_ws, wsum, (size_t)L.Wt * sizeof(XYZZ), hipMemcpyDeviceToHost, s));
+    H2_CHECK(hipMemcpyAsync(h_sums, sums, (size_t)ns * sizeof(XYZZ), hipMemcpyDeviceToHost, s));
     return 0;
 }
+
+// sets per MSM and the host-side finish
+static inline uint32_t sets_per_msm(const MsmPlan& p) { return p.shared ? 1 : p.W; }
+static inline XYZZ finish_msm(const XYZZ* sums, const MsmPlan& p) { return p.shared ? sums[0] : combine_windows(sums, p); }
 
 // `count` independent MSMs of n <= 2^26 pairs each over the same bases (ParamsKZG::commit_lagrange for the
 // advice columns of one proof, plonk/prover.rs:361-365).  count == 1 runs the three stages back to back on the
 // caller's stream.  count > 1 pipelines whole MSMs over three streams with three workspace slots:
-//   aux1:  A(0) | A(1) | A(2) | ...            digits + sort + bounds      (memory-bound)
+//   aux1:  A(0) | A(1) | A(2) | ...            digits + sort                (memory-bound)
 //   s   :       | B(0) | B(1) | ...            accumulate                  (VALU-bound)
 //   aux2:              | C(0) | C(1) | ...     reduce + copy-out           (latency-bound, few waves)
 // so that every accumulate launch is full-size while the sort of the next MSM and the reduction of the previous
 // one run underneath it.
 // scalars_on_host: d_scalars[j] are host pointers, uploaded into three device slots ahead of stage A.
-static int msm_batch_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, const Affine* d_bases, size_t n, size_t count, XYZZ* h_out,
-                           hipStream_t s) {
+static int msm_batch_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, const Affine* d_points, const MsmTable* tab, size_t n,
+                           size_t count, XYZZ* h_out, hipStream_t s) {
     MsmLayout L;
-    int rc = msm_layout(n, s, &L);
+    int rc = msm_layout(n, &L, 1, tab);
     if (rc) return rc;
     const size_t n_slots = count < 3 ? count : 3;
     for (size_t k = 0; k < n_slots; k++) {
@@ -595,7 +957,8 @@ static int msm_batch_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_h
         *out = dst;
         return 0;
     };
-    rc = c->host_ws.ensure(count * L.p.W * sizeof(XYZZ));
+    const uint32_t spm = sets_per_msm(L.p);
+    rc = c->host_ws.ensure(count * spm * sizeof(XYZZ));
     if (rc) return rc;
     XYZZ* h_ws = (XYZZ*)c->host_ws.p;
     rc = c->ws_acquire(s);
@@ -605,8 +968,8 @@ static int msm_batch_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_h
         char* base = (char*)c->msm_slot[0].p;
         const Fe* sc;
         if ((rc = scalars_for(0, s, &sc))) return rc;
-        if ((rc = msm_stage_a(c, L, base, &sc, s))) return rc;
-        if ((rc = msm_stage_b(c, L, base, d_bases, s))) return rc;
+        if ((rc = msm_stage_a(c, L, base, &sc, tab, s))) return rc;
+        if ((rc = msm_stage_b(c, L, base, d_points, s))) return rc;
         if ((rc = msm_stage_c(c, L, base, h_ws, s))) return rc;
     } else {
         // Three internal streams.  A full-size accumulate holds every wave slot for ~0.65 ms at a time, so the other
@@ -625,31 +988,31 @@ static int msm_batch_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_h
             if (j >= 3) H2_CHECK(hipStreamWaitEvent(a1, ev[3 + 3 * (j - 3)], 0));  // slot reuse: C(j-3) has drained it
             const Fe* sc;
             if ((rc = scalars_for(j, a1, &sc))) return rc;
-            if ((rc = msm_stage_a(c, L, base, &sc, a1))) return rc;
+            if ((rc = msm_stage_a(c, L, base, &sc, tab, a1))) return rc;
             H2_CHECK(hipEventRecord(ev[1 + 3 * j], a1));
             H2_CHECK(hipStreamWaitEvent(sb, ev[1 + 3 * j], 0));
-            if ((rc = msm_stage_b(c, L, base, d_bases, sb))) return rc;
+            if ((rc = msm_stage_b(c, L, base, d_points, sb))) return rc;
             H2_CHECK(hipEventRecord(ev[2 + 3 * j], sb));
             H2_CHECK(hipStreamWaitEvent(a2, ev[2 + 3 * j], 0));
-            if ((rc = msm_stage_c(c, L, base, h_ws + j * L.p.W, a2))) return rc;
+            if ((rc = msm_stage_c(c, L, base, h_ws + j * spm, a2))) return rc;
             H2_CHECK(hipEventRecord(ev[3 + 3 * j], a2));
         }
         H2_CHECK(hipStreamWaitEvent(s, ev[3 + 3 * (count - 1)], 0));  // C stages are in order on aux2
     }
     c->timer_end(t_all, s);
     H2_CHECK(hipStreamSynchronize(s));
-    for (size_t j = 0; j < count; j++) h_out[j] = combine_windows(h_ws + j * L.p.W, L.p);
+    for (size_t j = 0; j < count; j++) h_out[j] = finish_msm(h_ws + j * spm, L.p);
     return c->ws_release(s);
 }
 
-// Small MSMs over the same bases, fused: the `count` MSMs run as ONE pass of the three stages whose windows are the
-// windows of all of them (window j * W + w of the run is window w of MSM j).  The bucket reduction is a chain of ~60
-// dependent EC operations -- 0.43 ms whatever the size -- and dominates a 2^17-pair MSM; pipelining whole MSMs over streams
-// only overlaps those chains, fusing pays for one.  Sort and accumulate become one large launch each.
-static int msm_fused_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, const Affine* d_bases, size_t n, size_t count, XYZZ* h_out,
-                           hipStream_t s) {
+// Small MSMs over the same bases, fused: the `count` MSMs run as ONE pass of the three stages whose bucket sets are
+// the sets of all of them.  The bucket reduction is a chain of dependent EC operations -- its duration hardly
+// depends on the size -- and dominates a 2^17-pair MSM; pipelining whole MSMs over streams only overlaps those
+// chains, fusing pays for one.  Sort and accumulate become one large launch each.
+static int msm_fused_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, const Affine* d_points, const MsmTable* tab, size_t n,
+                           size_t count, XYZZ* h_out, hipStream_t s) {
     MsmLayout L;
-    int rc = msm_layout(n, s, &L, (uint32_t)count);
+    int rc = msm_layout(n, &L, (uint32_t)count, tab);
     if (rc) return rc;
     if ((rc = c->msm_slot[0].ensure(L.total))) return rc;
     std::vector<const Fe*> list(d_scalars, d_scalars + count);
@@ -662,45 +1025,67 @@ static int msm_fused_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_h
             list[j] = dst;
         }
     }
-    if ((rc = c->host_ws.ensure((size_t)L.Wt * sizeof(XYZZ)))) return rc;
+    if ((rc = c->host_ws.ensure((size_t)L.n_sets * sizeof(XYZZ)))) return rc;
     XYZZ* h_ws = (XYZZ*)c->host_ws.p;
     char* base = (char*)c->msm_slot[0].p;
     int t_all = c->timer_begin("msm_total", s);
-    if ((rc = msm_stage_a(c, L, base, list.data(), s))) return rc;
-    if ((rc = msm_stage_b(c, L, base, d_bases, s))) return rc;
+    if ((rc = msm_stage_a(c, L, base, list.data(), tab, s))) return rc;
+    if ((rc = msm_stage_b(c, L, base, d_points, s))) return rc;
     if ((rc = msm_stage_c(c, L, base, h_ws, s))) return rc;
     c->timer_end(t_all, s);
     H2_CHECK(hipStreamSynchronize(s));
-    for (size_t j = 0; j < count; j++) h_out[j] = combine_windows(h_ws + j * L.p.W, L.p);
+    const uint32_t spm = sets_per_msm(L.p);
+    for (size_t j = 0; j < count; j++) h_out[j] = finish_msm(h_ws + j * spm, L.p);
     return c->ws_release(s);
 }
 
 static bool g_fuse_small = true;
 void msm_set_fuse_small(bool on) { g_fuse_small = on; }
 
-// count MSMs over the same bases for device-resident inputs; results (XYZZ) to host memory.
+// count MSMs over the same bases for device-resident inputs; results (XYZZ) to host memory.  tab != nullptr: the
+// fixed-base form over tab's table (d_bases is then unused).
 int msm_batch_device(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, const Affine* d_bases, size_t n, size_t count, XYZZ* h_out,
-                     hipStream_t s) {
+                     hipStream_t s, const MsmTable* tab) {
     for (size_t j = 0; j < count; j++) h_out[j] = xyzz_identity();
     if (n == 0 || count == 0) return 0;
-    // the pair index lives in 31 bits and the sort counts in int: split very large inputs
+    if (tab && n > tab->stride) {
+        set_error("msm: %zu pairs exceed the %zu points of the fixed-base table", n, tab->stride);
+        return 1;
+    }
+    // the entry index lives in 31 bits: split very large inputs
     const size_t max_chunk = g_max_chunk;
     std::vector<const Fe*> ptrs(count);
     std::vector<XYZZ> part(count);
     for (size_t o = 0; o < n; o += max_chunk) {
         size_t m = n - o < max_chunk ? n - o : max_chunk;
         for (size_t j = 0; j < count; j++) ptrs[j] = d_scalars[j] + o;
-        // up to 2^18 pairs each: fused runs of at most 2^26 (pair, window) entries; larger MSMs: pipelined over streams
-        const size_t per_msm = m * make_plan(m, true).W;
-        const size_t fuse_max = per_msm ? ((size_t)1 << 26) / per_msm : 0;
+        MsmTable sub;
+        const MsmTable* tsub = nullptr;
+        const Affine* points = d_bases ? d_bases + o : nullptr;
+        if (tab) {
+            sub = *tab;
+            sub.table = tab->table + o;  // row j of the sub-table starts at table + j * stride + o
+            tsub = &sub;
+            points = sub.table;
+        }
+        // up to 2^18 pairs each: fused runs of at most 2^26 entries, MSM_MAX_C1 << MSM_MAX_L buckets and MSM_MAX_C1
+        // bucket sets; larger MSMs: pipelined over streams
+        const MsmPlan fp = make_plan(m, true, tsub);
+        const size_t per_msm = m * fp.W;
+        const size_t sets = fp.shared ? 1 : fp.W;
+        size_t fuse_max = per_msm ? ((size_t)1 << 26) / per_msm : 0;
+        const size_t by_buckets = (((size_t)MSM_MAX_C1 << MSM_MAX_L) >> fp.cb) / sets, by_sets = MSM_MAX_C1 / sets;
+        if (fuse_max > by_buckets) fuse_max = by_buckets;
+        if (fuse_max > by_sets) fuse_max = by_sets;
         if (g_fuse_small && count > 1 && m <= ((size_t)1 << 18) && fuse_max >= 2) {
             for (size_t j0 = 0; j0 < count; j0 += fuse_max) {
                 const size_t g = count - j0 < fuse_max ? count - j0 : fuse_max;
-                int rc = msm_fused_chunk(c, ptrs.data() + j0, scalars_on_host, d_bases + o, m, g, part.data() + j0, s);
+                int rc = g == 1 ? msm_batch_chunk(c, ptrs.data() + j0, scalars_on_host, points, tsub, m, 1, part.data() + j0, s)
+                                : msm_fused_chunk(c, ptrs.data() + j0, scalars_on_host, points, tsub, m, g, part.data() + j0, s);
                 if (rc) return rc;
             }
         } else {
-            int rc = msm_batch_chunk(c, ptrs.data(), scalars_on_host, d_bases + o, m, count, part.data(), s);
+            int rc = msm_batch_chunk(c, ptrs.data(), scalars_on_host, points, tsub, m, count, part.data(), s);
             if (rc) return rc;
         }
         for (size_t j = 0; j < count; j++) xyzz_add(h_out[j], part[j]);
@@ -709,8 +1094,33 @@ int msm_batch_device(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, c
 }
 
 // Sum of coeffs[i]*bases[i] for device-resident inputs; result (XYZZ) to host memory.
-int msm_device(Ctx* c, const Fe* d_scalars, const Affine* d_bases, size_t n, XYZZ* h_out, hipStream_t s) {
-    return msm_batch_device(c, &d_scalars, false, d_bases, n, 1, h_out, s);
+int msm_device(Ctx* c, const Fe* d_scalars, const Affine* d_bases, size_t n, XYZZ* h_out, hipStream_t s, const MsmTable* tab) {
+    return msm_batch_device(c, &d_scalars, false, d_bases, n, 1, h_out, s, tab);
+}
+
+// Build the fixed-base table for n device-resident points: rows 0..W-1 of n points each, row j = 2^(pos_j) * P with pos_j the
+// first bit of window j (MsmPlan).
+// Row 0 is a copy of the points.  Rows are built one from the other (c doublings in XYZZ, then one batched
+// normalisation back to affine), in slices of 2^22 points so the XYZZ scratch stays at 512 MB.
+int msm_table_build(Ctx* c, const Affine* d_points, size_t n, uint32_t cw, Affine* d_table, hipStream_t s) {
+    const uint32_t W = (255 + cw - 1) / cw, q = 255 - W * (cw - 1);
+    H2_CHECK(hipMemcpyAsync(d_table, d_points, n * sizeof(Affine), hipMemcpyDeviceToDevice, s));
+    const size_t slice = (size_t)1 << 22;
+    const size_t m_max = n < slice ? n : slice;
+    int rc = c->ecfft_ws.ensure(m_max * sizeof(XYZZ));
+    if (rc) return rc;
+    if ((rc = c->ws_acquire(s))) return rc;
+    XYZZ* tmp = (XYZZ*)c->ecfft_ws.p;
+    for (uint32_t j = 1; j < W; j++) {
+        for (size_t o = 0; o < n; o += slice) {
+            const size_t m = n - o < slice ? n - o : slice;
+            hipLaunchKernelGGL(msm_table_step_kernel, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, s, d_table + (size_t)(j - 1) * n + o, tmp,
+                               (uint32_t)m, (j - 1) < q ? cw : cw - 1);  // window j starts width(j - 1) bits above window j - 1
+            H2_CHECK(hipGetLastError());
+            if ((rc = ec_normalize_device(tmp, d_table + (size_t)j * n + o, m, s))) return rc;
+        }
+    }
+    return c->ws_release(s);
 }
 
 }  // namespace h2

@@ -23,7 +23,7 @@
 #include <vector>
 
 #include "../../include/halo2hip.h"
-#include "../csrc/field.cuh"  // host-side Fr arithmetic for domain constants (no HIP needed)
+#include "../csrc/ec.cuh"  // host-side Fr / Fq / G1 arithmetic for domain constants and SRS checks (no HIP needed)
 
 namespace halo2_proofs {
 
@@ -230,9 +230,15 @@ class ParamsKZG {
     ParamsKZG& operator=(const ParamsKZG&) = delete;
     ~ParamsKZG() { unpin(); }
 
+    // SerdeFormat (helpers.rs:8-21); `Processed` (compressed points) is not on this path
+    enum class SerdeFormat { RawBytes, RawBytesUnchecked };
+
     // Params::read = read_custom(reader, SerdeFormat::RawBytes) (poly/kzg/commitment.rs:160-244, :300-302):
-    // k as u32 LE, then g, g_lagrange as 64-B Montgomery points, then g2, s_g2 (128 B each)
-    static void read(std::istream& reader, ParamsKZG& p) {
+    // k as u32 LE, then g, g_lagrange as 64-B Montgomery points, then g2, s_g2 (128 B each).  RawBytes checks that
+    // every coordinate is below the modulus and every point lies on the curve (helpers.rs:15-18, read_raw);
+    // RawBytesUnchecked performs no checks (:19-20).
+    static void read(std::istream& reader, ParamsKZG& p) { read_custom(reader, p, SerdeFormat::RawBytes); }
+    static void read_custom(std::istream& reader, ParamsKZG& p, SerdeFormat format) {
         uint8_t kb[4];
         reader.read(reinterpret_cast<char*>(kb), 4);
         if (!reader) throw std::runtime_error("ParamsKZG::read: short read");
@@ -247,7 +253,19 @@ class ParamsKZG {
         reader.read(reinterpret_cast<char*>(p.g2.data()), 128);
         reader.read(reinterpret_cast<char*>(p.s_g2.data()), 128);
         if (!reader) throw std::runtime_error("ParamsKZG::read: short read");
+        if (format == SerdeFormat::RawBytes) {
+            for (const auto* v : {&p.g, &p.g_lagrange})
+                for (const G1Affine& pt : *v)
+                    if (!point_is_valid(pt)) throw std::runtime_error("ParamsKZG::read: invalid point encoding");
+        }
         p.pin();
+    }
+
+    // read_raw's checks for one G1Affine: limbs below the modulus, point on y^2 = x^3 + 3 (the identity is (0, 0))
+    static bool point_is_valid(const G1Affine& pt) {
+        h2::Affine a;
+        std::memcpy(&a, &pt, 64);
+        return h2::fe_is_canonical<h2::FqP>(a.x) && h2::fe_is_canonical<h2::FqP>(a.y) && h2::affine_on_curve(a);
     }
 
     // downsize (poly/kzg/commitment.rs:267-275)
@@ -295,7 +313,12 @@ class ParamsKZG {
     bool pinned_ = false;
     void pin() {
         engine_check(h2hip_bases_pin(g[0].x, g.size()), "bases_pin(g)");
-        engine_check(h2hip_bases_pin(g_lagrange[0].x, g_lagrange.size()), "bases_pin(g_lagrange)");
+        if (int rc = h2hip_bases_pin(g_lagrange[0].x, g_lagrange.size())) {  // do not leave g pinned behind a failed object
+            std::string msg = std::string("bases_pin(g_lagrange): ") + h2hip_last_error();
+            (void)h2hip_bases_unpin(g[0].x);
+            (void)rc;
+            throw std::runtime_error(msg);
+        }
         pinned_ = true;
     }
     void unpin() {

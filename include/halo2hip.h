@@ -16,9 +16,19 @@
  * Conventions: every function returns 0 on success and a non-zero H2HIP_E* code otherwise
  * (never throws / unwinds; the Rust shim falls back to the original CPU body on non-zero).
  * h2hip_last_error() describes the last failure on the calling thread.  All entry points are
- * thread-safe and blocking; one process drives one GPU (the current HIP device at init).
+ * thread-safe and blocking.  One process drives the GPUs named at h2hip_init: host-pointer MSMs
+ * are sharded over all of them inside the call (the fan-out and fold best_multiexp performs over
+ * rayon threads, arithmetic.rs:137-153), everything else runs on the first device, or -- for the
+ * _device entry points -- on the device that owns the pointers.
  * There is no CPU fallback inside the library: without a usable GPU every compute entry
  * point fails with H2HIP_EDEVICE.
+ *
+ * Environment (read at init): HALO2_HIP_DEVICES="0,1,.." device list when h2hip_init gets none;
+ * HALO2_HIP_MULTI_GPU_MIN_N (default 2^18) smallest MSM that is sharded; HALO2_HIP_GATHER=rccl|host
+ * how the devices' 96-byte partials meet; HALO2_HIP_MSM_WINDOW; HALO2_HIP_FIXED_BASE=0 and
+ * HALO2_HIP_TABLE_MAX_GB for h2hip_bases_pin's window tables; HALO2_HIP_MSM_MIN_N /
+ * HALO2_HIP_NTT_MIN_LOGN thresholds the Rust shim reads back through h2hip_msm_min_n() /
+ * h2hip_ntt_min_log_n(); HALO2_HIP_ROCTX=1 roctx ranges around every entry point.
  */
 #ifndef HALO2HIP_H
 #define HALO2HIP_H
@@ -37,15 +47,23 @@ extern "C" {
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
 
-/* Bind the engine to a GPU.  device_ids == NULL or n_devices == 0: use the calling thread's
- * current HIP device.  Idempotent.  (Multi-GPU MSM runs one process per GPU, see
- * h2hip_g1_fold.) */
+/* Bind the engine to n_devices GPUs (HIP device ordinals).  device_ids == NULL or n_devices == 0: the
+ * HALO2_HIP_DEVICES list, else the calling thread's current HIP device.  Idempotent for the same list;
+ * a different list needs h2hip_shutdown first (H2HIP_EINVAL otherwise).  With more than one device the
+ * engine starts one host thread and one stream per device and, when librccl is present, one RCCL
+ * communicator per device (ncclCommInitAll) for the gather of the MSM partials.  An id out of range or
+ * listed twice is H2HIP_EINVAL. */
 int h2hip_init(const int* device_ids, int n_devices);
 void h2hip_shutdown(void);
 const char* h2hip_last_error(void);
 const char* h2hip_version(void);
 /* number of visible HIP devices, or -1 when the runtime reports an error */
 int h2hip_device_count(void);
+/* devices the engine is bound to (0 before init) */
+int h2hip_num_devices(void);
+/* dispatch thresholds for the shim: below them the reference's CPU body is the faster path */
+size_t h2hip_msm_min_n(void);
+uint32_t h2hip_ntt_min_log_n(void);
 
 /* ---- best_multiexp: arithmetic.rs:132-159 ------------------------------------------------ */
 
@@ -58,12 +76,22 @@ int h2hip_device_count(void);
  * (they depend on rayon's thread count, arithmetic.rs:153). */
 int h2hip_msm_bn254(const uint64_t* scalars, const uint64_t* bases_xy, size_t n, uint64_t out_xyz[12]);
 
-/* Keep a copy of `bases_xy[0..n)` on the GPU, keyed by the host pointer: later
- * h2hip_msm_bn254 calls whose bases pointer equals `bases_xy` (and n' <= n) skip the upload.
- * For ParamsKZG::{g, g_lagrange} (poly/kzg/commitment.rs:26-27), which live as long as the
- * params; call unpin before the Vec is dropped or mutated (downsize, :267-275). */
+/* Keep `bases_xy[0..n)` on the GPU(s), keyed by the host pointer: later h2hip_msm_bn254[_batch] calls
+ * whose bases pointer equals `bases_xy` (and n' <= n) skip the upload.  For ParamsKZG::{g, g_lagrange}
+ * (poly/kzg/commitment.rs:26-27), which live as long as the params; call unpin before the Vec is dropped
+ * or mutated (downsize, :267-275).  With several devices each one keeps its contiguous share.
+ * Pinning also builds the fixed-base window table 2^(c j) * P_i (j < W = 254/c + 1; 16 <= n <= 2^26; W * n * 64
+ * bytes of HBM, e.g. 0.8 GB at 2^20, 12 GB at 2^24): all windows of an MSM then share one bucket set, the
+ * windows are wider (c = 20 instead of 16 at 2^20) and no Horner pass is needed.
+ * The cache is safe against stale pointers: every lookup compares 16 sampled points of the caller's array
+ * with the ones seen at pin time and falls back to a plain upload (dropping the entry) on a mismatch. */
 int h2hip_bases_pin(const uint64_t* bases_xy, size_t n);
-int h2hip_bases_unpin(const uint64_t* bases_xy);
+/* the same for points that already live in HBM (keyed by the device pointer, used by the _device MSMs);
+ * the points are copied, the caller's buffer is not referenced after the call returns */
+int h2hip_bases_pin_device(const void* d_bases_xy, size_t n, void* stream);
+int h2hip_bases_unpin(const void* bases_xy);
+/* what a pinned pointer holds: points, window width / windows of its table (0 / 0 without one), bytes of HBM */
+int h2hip_bases_pinned_info(const void* bases_xy, size_t* n_points, uint32_t* window_bits, uint32_t* windows, size_t* device_bytes);
 
 /* Same computation on device-resident inputs (scalars n x 32 B, bases n x 64 B in HBM);
  * `stream` is a hipStream_t; NULL is HIP's default (null) stream, as everywhere in HIP.  All
@@ -85,7 +113,8 @@ int h2hip_msm_bn254_batch_device(const void* const* d_scalars, const void* d_bas
 int h2hip_g1_batch_normalize(const uint64_t* xyz, size_t k, uint64_t* xy);
 
 /* Left fold of k Jacobian partial sums from the identity -- the fold at arithmetic.rs:153.
- * Multi-GPU MSM: each rank computes its shard's partial with h2hip_msm_bn254[_device], the
+ * Inside one process h2hip_msm_bn254 does this itself over the devices of h2hip_init.  With one process per
+ * GPU (bench.py --gpus N) each rank computes its shard's partial with h2hip_msm_bn254[_device], the
  * 96-byte partials are all-gathered (RCCL, bytes), and every rank folds them with this. */
 int h2hip_g1_fold(const uint64_t* partials_xyz, size_t k, uint64_t out_xyz[12]);
 /* Curve::to_affine; identity -> (0,0) */
@@ -248,10 +277,12 @@ int h2hip_gen_points_device(uint64_t seed, uint64_t start, size_t n, void* d_out
 
 /* ---- tuning and measurement ----------------------------------------------------------------- */
 
-/* MSM window width in bits (2..22); 0 restores the size-based default */
+/* MSM window width in bits (2..24); 0 restores the size-based default.  Applies to the plain form at once
+ * and to window tables built by later h2hip_bases_pin* calls. */
 int h2hip_set_msm_window(uint32_t c);
-/* window width the engine would use for n pairs */
+/* window width the engine would use for n pairs: plain form / a window table over n pinned points */
 uint32_t h2hip_get_msm_window(size_t n);
+uint32_t h2hip_get_msm_window_fixed_base(size_t n);
 /* Per-stage HIP-event timers recorded on the stream each kernel group is launched on.
  * Stages: "ntt", "msm_total", "msm_digits", "msm_sort", "msm_accum", "msm_heavy", "msm_reduce", "g_to_lagrange". */
 int h2hip_profile_enable(int on);
@@ -262,6 +293,10 @@ int h2hip_profile_get(const char* stage, double* total_ms, uint64_t* count);
 
 /* split MSM inputs above m pairs into consecutive chunks (default 2^26, the 31-bit pair-index limit; 0 restores it) */
 int h2hip_debug_set_msm_max_chunk(size_t m);
+/* buckets with more than (entries of the MSM) / d entries take the chunked path (default d = 32768; 0 restores it) */
+int h2hip_debug_set_msm_heavy_div(size_t d);
+/* target entries per coarse bin of the MSM's two-level sort (default 8192; 0 restores it) */
+int h2hip_debug_set_msm_bin_entries(size_t d);
 /* CUs reserved for the sort / reduce streams of a batched MSM (0 = none: every split measured slower) */
 int h2hip_debug_set_reserved_cus(uint32_t k);
 /* batches of MSMs of up to 2^18 pairs: fused into one run (1, default) or pipelined over streams (0) */

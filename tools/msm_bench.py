@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""tools/msm_bench.py -- stage times of one device-resident MSM, plain form and fixed-base form (window table built by
+h2hip_bases_pin_device), for a list of sizes and optional window overrides.  Prints one JSON object per line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from __graft_entry__ import load_pkg  # noqa: E402
+
+STAGES = ("msm_total", "msm_digits", "msm_sort", "msm_accum", "msm_heavy", "msm_reduce")
+
+
+def time_msm(h2, ds, dp, reps):
+    for _ in range(2):
+        r = h2.msm_device(ds, dp)
+    h2.profile_enable(True)
+    h2.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = h2.msm_device(ds, dp)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    h2.profile_enable(False)
+    st = {}
+    for s in STAGES:
+        tot, cnt = h2.profile_get(s)
+        st[s] = round(tot / cnt, 4) if cnt else None
+    return ms, st, r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log-n", type=int, nargs="+", default=[17, 20])
+    ap.add_argument("--windows", type=int, nargs="*", default=[0], help="window overrides to try (0 = default)")
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--no-plain", action="store_true")
+    ap.add_argument("--no-fixed", action="store_true")
+    ap.add_argument("--heavy-div", type=int, default=0)
+    ap.add_argument("--bin-entries", type=int, default=0)
+    ap.add_argument("--l1-mode", type=int, default=0)
+    ap.add_argument("--skew", action="store_true", help="prover-like scalars: 90 %% zero, 5 %% in {1, 2}, 5 %% uniform")
+    args = ap.parse_args()
+    h2 = load_pkg()
+    h2.init(0)
+    import ctypes
+    h2.lib().h2hip_debug_set_msm_heavy_div(ctypes.c_size_t(args.heavy_div))
+    h2.lib().h2hip_debug_set_msm_bin_entries(ctypes.c_size_t(args.bin_entries))
+    h2.lib().h2hip_debug_set_msm_l1_mode(ctypes.c_int(args.l1_mode))
+    for lg in args.log_n:
+        n = 1 << lg
+        ds = h2.gen_scalars_device(0x5EED0001, n)
+        dp = h2.gen_points_device(0x5EED0002, n)
+        if args.skew:
+            r = torch.rand(n, device="cuda")
+            small = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+            ds = torch.where((r < 0.9)[:, None], small, ds)
+        torch.cuda.synchronize()
+        ref = None
+        for c in args.windows:
+            h2.set_msm_window(c)
+            if not args.no_plain and not (c > 21):
+                ms, st, r = time_msm(h2, ds, dp, args.reps)
+                aff = h2.g1_to_affine(r)
+                ref = aff if ref is None else ref
+                print(json.dumps({"form": "plain", "log_n": lg, "c": c or h2.get_msm_window(n), "ms": round(ms, 4), "stages": st,
+                                  "same_result": bool(np.array_equal(aff, ref))}), flush=True)
+            if not args.no_fixed:
+                t0 = time.perf_counter()
+                h2.bases_pin_device(dp)
+                t_pin = time.perf_counter() - t0
+                info = h2.bases_pinned_info(dp)
+                ms, st, r = time_msm(h2, ds, dp, args.reps)
+                aff = h2.g1_to_affine(r)
+                ref = aff if ref is None else ref
+                print(json.dumps({"form": "fixed-base", "log_n": lg, "c": info[1], "W": info[2], "table_MB": round(info[3] / 2**20, 1),
+                                  "pin_s": round(t_pin, 3), "ms": round(ms, 4), "stages": st, "same_result": bool(np.array_equal(aff, ref))}),
+                      flush=True)
+                h2.bases_unpin_device(dp)
+        h2.set_msm_window(0)
+        del ds, dp
+
+
+if __name__ == "__main__":
+    main()
