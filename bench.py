@@ -4,19 +4,23 @@
 Step = one pass of the hot path over one batch of synthetic input: one BN254 G1 MSM of
 2^LOG_N pairs per GPU (BASELINE.json configs[1]: 2^20 on one MI355X), inputs generated in HBM
 before the timed region (SplitMix64 scalars / try-and-increment points).
-With N > 1 ranks each rank runs the same-size shard (weak scaling), the 96-byte partials are
-all-gathered over RCCL and folded on every rank (arithmetic.rs:153).
+The bases are pinned the way a ParamsKZG pins g / g_lagrange (h2hip_bases_pin_device: the
+engine's fixed-base window table, built before the timed region; `--form plain` times the
+unpinned form).  With N > 1 ranks each rank runs the same-size shard (weak scaling), the
+96-byte partials are all-gathered over RCCL and folded on every rank (arithmetic.rs:153).
+`python bench.py --gpus N` started bare spawns the N ranks itself.
 
 Prints ONE JSON line on rank 0.  `value` = bucket-accumulation G1 adds per second over the
-whole job = N * n * W / t (W = 254//c + 1 signed windows at the engine's window width c;
-SURVEY.md 8(d)); pairs/s and the NTT figure ride along as extra keys.  `roofline` prices the
-dominant kernel (msm_accum_kernel) at its algorithmic 96 B per pair against 8 TB/s, timed with
-HIP events on the stream it is launched on; `cpu_baseline` is the oracle's restatement of the
-reference's rayon path timed on this box's host cores.
+whole job = N * n * W / t (W = ceil(255 / c) signed windows at the engine's window width c;
+SURVEY.md 8(d)); pairs/s, the other sizes and the NTT figures ride along as extra keys.
+`roofline` prices the dominant kernel (msm_accum_kernel) at its algorithmic 96 B per pair
+against 8 TB/s, timed with HIP events on the stream it is launched on; `cpu_baseline` is the
+oracle's restatement of the reference's rayon path timed on this box's host cores.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,6 +40,7 @@ MSM_BYTES_PER_PAIR = 96  # 32 B scalar + 64 B affine point, read once (SURVEY.md
 NTT_BYTES_PER_ELEM = 64  # one 32 B read + one 32 B write per transform
 FIELD_MUL_PER_BUCKET_ADD = 9.2  # XYZZ mixed add: 7 products + 2 squares + one two-product single-reduction form (csrc/ecu.cuh)
 FIELD_MUL_PEAK_G = 179.0  # measured peak of csrc/fieldu.cuh's multiplier on MI355X, G multiplies/s (tools/mul_rate.hip)
+STAGES = ("msm_total", "msm_digits", "msm_sort", "msm_accum", "msm_heavy", "msm_reduce")
 
 
 def cpu_model():
@@ -51,7 +56,7 @@ def cpu_model():
 
 def pmc_traffic(workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass
-    (profiles/*_pmc_traffic.json, made by tools/pmc_traffic.py), or None when absent."""
+    (profiles/pmc_traffic.json, made by tools/pmc_traffic.py), or None when absent."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
@@ -61,17 +66,87 @@ def pmc_traffic(workload):
         return None
 
 
+def windows_of(c):
+    return (255 + c - 1) // c
+
+
 def spawn_ranks(n_ranks):
     """Start `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>` as a child process and return its
     exit code.  Called before anything in this process has touched the GPU (torch is imported, no device call made)."""
     import socket
-    import subprocess
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd)
+
+
+def timed_msm(h2, ds, dp, reps, warm=2):
+    """ms per h2hip_msm_bn254_device call (wall clock around the blocking calls) and the per-stage HIP-event times"""
+    for _ in range(warm):
+        r = h2.msm_device(ds, dp)
+    h2.profile_enable(True)
+    h2.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = h2.msm_device(ds, dp)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    h2.profile_enable(False)
+    st = {}
+    for s in STAGES:
+        tot, cnt = h2.profile_get(s)
+        st[s] = tot / cnt if cnt else None
+    return ms, st, r
+
+
+def msm_roofline(n, accum_ms, workload=None):
+    ach = MSM_BYTES_PER_PAIR * n / (accum_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+            "traffic": pmc_traffic(workload) if workload else None, "kernel": "msm_accum_kernel", "kernel_ms": accum_ms,
+            "algorithmic_bytes_per_launch": MSM_BYTES_PER_PAIR * n}
+
+
+def inlib_child(args):
+    """--inlib N: ONE process drives N GPUs through the C ABI -- h2hip_init(ids, N), host-pointer h2hip_msm_bn254 over bases
+    pinned across the devices, partials gathered with RCCL inside the library.  Prints one JSON object."""
+    h2 = load_pkg()
+    n_dev = args.inlib
+    ids = list(range(n_dev))
+    if h2.device_count() < n_dev:
+        ids = [i % max(1, h2.device_count()) for i in range(n_dev)]  # rehearsal on a smaller box (needs the switch below)
+        os.environ.setdefault("HALO2_HIP_ALLOW_DUPLICATE_DEVICES", "1")
+    h2.init(ids)
+    n = n_dev << args.log_n  # weak scaling: 2^log_n pairs per device
+    sc = np.empty((n, 4), dtype=np.uint64)
+    bs = np.empty((n, 8), dtype=np.uint64)
+    torch.cuda.set_device(ids[0])
+    chunk = 1 << 22
+    for o in range(0, n, chunk):  # the synthetic inputs, generated on the first device, handed over as host arrays
+        m = min(chunk, n - o)
+        sc[o:o + m] = h2.to_numpy_u64(h2.gen_scalars_device(0x5EED0001, m, start=o))
+        bs[o:o + m] = h2.to_numpy_u64(h2.gen_points_device(0x5EED0002, m, start=o))
+    t0 = time.perf_counter()
+    h2.bases_pin(bs)
+    pin_s = time.perf_counter() - t0
+    info = h2.bases_pinned_info(bs)
+    out = h2.best_multiexp(sc, bs)
+    times = []
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        out = h2.best_multiexp(sc, bs)
+        times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    W = info[2]
+    res = {"n_devices": n_dev, "device_ids": ids, "pairs_total": n, "window_bits": info[1], "windows": W, "pin_s": pin_s,
+           "table_bytes_total": info[3], "ms_per_msm": t * 1e3, "value": n * W / t, "unit": "G1-adds/s", "pairs_per_s": n / t,
+           "gather": os.environ.get("HALO2_HIP_GATHER", "rccl"),
+           "note": "host-pointer h2hip_msm_bn254 (scalars cross PCIe inside the call: %d MiB per device), bases pinned per device" % ((32 << args.log_n) >> 20),
+           "result_affine_x0": int(h2.g1_to_affine(out)[0])}
+    h2.bases_unpin(bs)
+    print("INLIB " + json.dumps(res))
 
 
 def main():
@@ -82,14 +157,21 @@ def main():
     ap.add_argument("--log-n", type=int, default=20, help="pairs per GPU = 2^log_n")
     ap.add_argument("--ntt-log-n", type=int, default=22)
     ap.add_argument("--window", type=int, default=0, help="MSM window bits (0 = engine default)")
+    ap.add_argument("--form", default="fixed", choices=["fixed", "plain"], help="fixed: bases pinned with their window table (the KZG "
+                    "commit path); plain: arbitrary bases, one bucket set per window")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                     "N > 1 path on a single-GPU box, where every rank then uses cuda:0)")
     ap.add_argument("--batch", type=int, default=8, help="also time a pipelined batch of this many MSMs (extra key; 0/1 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--no-sizes", action="store_true", help="skip the other sizes (2^22..2^26 MSM, 2^20..2^26 NTT, host-pointer figures, k = 17 trace)")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the evaluate_h / g_to_lagrange legs (SURVEY.md 8(f).3, (f).4)")
+    ap.add_argument("--no-inlib", action="store_true", help="N > 1: skip the single-process N-device leg (h2hip_init with N ids)")
+    ap.add_argument("--inlib", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.inlib:
+        return inlib_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: this process has made no GPU call yet, so it may start the N ranks as fresh
         # child processes (one per GPU, the launch shape the driver uses) and hand their output and exit code through
@@ -119,12 +201,21 @@ def main():
         h2.set_msm_window(args.window)
 
     n = 1 << args.log_n
-    c = h2.get_msm_window(n)
-    W = 254 // c + 1
     # every rank draws its own shard of one global sequence (element index offset = rank * n)
     d_scalars = h2.gen_scalars_device(0x5EED0001, n, start=rank * n, device=dev)
     d_points = h2.gen_points_device(0x5EED0002, n, start=rank * n, device=dev)
     torch.cuda.synchronize()
+    pin = None
+    if args.form == "fixed":
+        t0 = time.perf_counter()
+        h2.bases_pin_device(d_points)
+        pin_s = time.perf_counter() - t0
+        info = h2.bases_pinned_info(d_points)
+        c, W = info[1], info[2]
+        pin = {"seconds": pin_s, "table_bytes": info[3], "note": "h2hip_bases_pin_device: W x n x 64 B window table, built once per ParamsKZG"}
+    else:
+        c = h2.get_msm_window(n)
+        W = windows_of(c)
 
     def step():
         part = h2.msm_device(d_scalars, d_points)
@@ -154,13 +245,32 @@ def main():
         elapsed = float(t.item())
 
     stages = {}
-    for st in ("msm_total", "msm_digits", "msm_sort", "msm_accum", "msm_heavy", "msm_reduce"):
+    for st in STAGES:
         ms, cnt = h2.profile_get(st)
         stages[st] = ms / cnt if cnt else None
 
-    # ---- batched commit: B MSMs over the same bases in one pipelined call, rank 0 only ----
+    solo = rank == 0 and world == 1
+
+    # ---- the other form of the same MSM (plain when the step is fixed-base and vice versa), rank 0, N = 1 ----
+    other_form = None
+    if solo:
+        if args.form == "fixed":
+            h2.bases_unpin_device(d_points)
+        else:
+            h2.bases_pin_device(d_points)
+        ms_o, st_o, r_o = timed_msm(h2, d_scalars, d_points, 10)
+        c_o = h2.get_msm_window(n) if args.form == "fixed" else h2.bases_pinned_info(d_points)[1]
+        other_form = {"form": "plain" if args.form == "fixed" else "fixed", "window_bits": c_o, "windows": windows_of(c_o), "ms_per_msm": ms_o,
+                      "value": n * windows_of(c_o) / (ms_o * 1e-3), "unit": "G1-adds/s", "stage_ms": st_o,
+                      "same_group_element": bool(np.array_equal(h2.g1_to_affine(r_o), h2.g1_to_affine(result)))}
+        if args.form == "fixed":
+            h2.bases_pin_device(d_points)
+        else:
+            h2.bases_unpin_device(d_points)
+
+    # ---- batched commit: B MSMs over the same bases in one call, rank 0 only ----
     batched = None
-    if rank == 0 and world == 1 and args.batch > 1 and args.log_n <= 22:
+    if solo and args.batch > 1 and args.log_n <= 22:
         B = args.batch
         cols = [h2.gen_scalars_device(0x5EED0001, n, start=(j + 1) * n, device=dev) for j in range(B)]
         h2.msm_batch_device(cols, d_points)
@@ -177,7 +287,7 @@ def main():
         # the prover's size (BASELINE.json configs[4], k = 17): 16 column commits as one fused batch, against one call each
         n17 = 1 << 17
         cols = [h2.gen_scalars_device(0x5EED0001, n17, start=(j + 1) * n17, device=dev) for j in range(16)]
-        pts17 = d_points[:n17]
+        pts17 = h2.gen_points_device(0x5EED0002, n17, device=dev)
 
         def timed(f, reps=3):
             f()
@@ -188,47 +298,103 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t1) / reps
 
-        t_fused = timed(lambda: h2.msm_batch_device(cols, pts17)) / 16
-        t_single = timed(lambda: [h2.msm_device(c_, pts17) for c_ in cols]) / 16
-        batched["k17"] = {"count": 16, "ms_per_msm": t_fused * 1e3, "ms_per_msm_one_call_each": t_single * 1e3,
-                          "note": "batches of up to 2^18 pairs run fused: one sort / accumulate / reduce over the windows of all MSMs"}
-        del cols
+        k17 = {"count": 16}
+        for form in ("plain", "fixed"):
+            if form == "fixed":
+                h2.bases_pin_device(pts17)
+            k17[form] = {"ms_per_msm_fused_batch": timed(lambda: h2.msm_batch_device(cols, pts17)) / 16 * 1e3,
+                         "ms_per_msm_one_call_each": timed(lambda: [h2.msm_device(c_, pts17) for c_ in cols]) / 16 * 1e3}
+        h2.bases_unpin_device(pts17)
+        k17["note"] = "batches of up to 2^18 pairs run fused: one sort / accumulate / reduce over the bucket sets of all MSMs"
+        batched["k17"] = k17
+        del cols, pts17
 
     # ---- NTT leg (BASELINE.json configs[2]: k = 22 NTT + iNTT), outside the MSM timed region ----
-    ntt = None
-    if not args.no_ntt and rank == 0:
-        from oracle import oracle
-        k = args.ntt_log_n
-        d, _ = oracle.domain_new(2, k)
+    def ntt_point(k, reps):
+        d = h2.EvaluationDomain.new(2, k)
         d_a = h2.gen_scalars_device(0x5EED0003, 1 << k, device=dev)
         for _ in range(2):
-            h2.ntt_device(d_a, d.fe("omega"), k)
-            h2.ifft_device(d_a, d.fe("omega_inv"), k, d.fe("ifft_divisor"))
+            h2.ntt_device(d_a, d.omega, k)
+            h2.ifft_device(d_a, d.omega_inv, k, d.ifft_divisor)
         torch.cuda.synchronize()
-        reps = 10
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            h2.ntt_device(d_a, d.fe("omega"), k)
-            h2.ifft_device(d_a, d.fe("omega_inv"), k, d.fe("ifft_divisor"))
+            h2.ntt_device(d_a, d.omega, k)
+            h2.ifft_device(d_a, d.omega_inv, k, d.ifft_divisor)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / (2 * reps)
-        ntt = {
-            "log_n": k,
-            "ms_per_transform": ms,
-            "elems_per_s": (1 << k) / (ms * 1e-3),
-            "roofline": {"bound": "hbm", "achieved": NTT_BYTES_PER_ELEM * (1 << k) / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": NTT_BYTES_PER_ELEM * (1 << k) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         # PMC bytes of one transform = two strided passes + the final pass (committed --pmc runs, 2^22 only)
-                         "traffic": (2 * st + fi) if (k == 22 and (st := pmc_traffic("ntt_2p22_strided")) and (fi := pmc_traffic("ntt_2p22_final")))
-                         else None},
-        }
-        del d_a
+        gbps = NTT_BYTES_PER_ELEM * (1 << k) / (ms * 1e-3) / 1e9
+        return {"log_n": k, "ms_per_transform": ms, "elems_per_s": (1 << k) / (ms * 1e-3),
+                "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                             # PMC bytes of one transform = sum over its passes (committed --pmc runs, 2^22 only)
+                             "traffic": pmc_traffic("ntt_2p22") if k == 22 else None}}
+
+    ntt = None
+    if not args.no_ntt and rank == 0:
+        ntt = ntt_point(args.ntt_log_n, 10)
+
+    # ---- the sizes DESIGN.md quotes, measured by this run (rank 0, N = 1) ----
+    sizes = None
+    if solo and not args.no_sizes:
+        sizes = {"msm": {}, "ntt": {}}
+        for lg in (22, 24, 26):
+            m = 1 << lg
+            ds = h2.gen_scalars_device(0x5EED0001, m, device=dev)
+            dp = h2.gen_points_device(0x5EED0002, m, device=dev)
+            torch.cuda.synchronize()
+            ent = {}
+            reps = 3 if lg >= 24 else 5
+            ms_p, st_p, r_p = timed_msm(h2, ds, dp, reps, warm=1)
+            cp = h2.get_msm_window(m)
+            ent["plain"] = {"window_bits": cp, "windows": windows_of(cp), "ms": ms_p, "g1_adds_per_s": m * windows_of(cp) / (ms_p * 1e-3),
+                            "pairs_per_s": m / (ms_p * 1e-3), "stage_ms": st_p, "roofline_frac": msm_roofline(m, st_p["msm_accum"])["frac"]}
+            t0 = time.perf_counter()
+            h2.bases_pin_device(dp)
+            pin_t = time.perf_counter() - t0
+            inf = h2.bases_pinned_info(dp)
+            ms_f, st_f, r_f = timed_msm(h2, ds, dp, reps, warm=1)
+            ent["fixed"] = {"window_bits": inf[1], "windows": inf[2], "table_bytes": inf[3], "pin_s": pin_t, "ms": ms_f,
+                            "g1_adds_per_s": m * inf[2] / (ms_f * 1e-3), "pairs_per_s": m / (ms_f * 1e-3), "stage_ms": st_f,
+                            "roofline_frac": msm_roofline(m, st_f["msm_accum"])["frac"],
+                            "same_group_element_as_plain": bool(np.array_equal(h2.g1_to_affine(r_p), h2.g1_to_affine(r_f)))}
+            h2.bases_unpin_device(dp)
+            sizes["msm"]["2^%d" % lg] = ent
+            del ds, dp
+            torch.cuda.empty_cache()
+        for k in (20, 24, 26):
+            sizes["ntt"]["2^%d" % k] = ntt_point(k, 5 if k < 26 else 3)
+            torch.cuda.empty_cache()
+        # host-pointer entry points (PCIe-inclusive, pageable caller memory): what the unpatched two-line drop-in pays
+        sc, bs = h2.to_numpy_u64(d_scalars).copy(), h2.to_numpy_u64(d_points).copy()
+
+        def host_ms(f, reps=5):
+            f()
+            ts = []
+            for _ in range(reps):
+                t1 = time.perf_counter()
+                f()
+                ts.append(time.perf_counter() - t1)
+            return sorted(ts)[len(ts) // 2] * 1e3
+
+        hp = {"msm_2p%d_unpinned_ms" % args.log_n: host_ms(lambda: h2.best_multiexp(sc, bs))}
+        h2.bases_pin(bs)
+        hp["msm_2p%d_pinned_ms" % args.log_n] = host_ms(lambda: h2.best_multiexp(sc, bs))
+        h2.bases_unpin(bs)
+        dk = h2.EvaluationDomain.new(2, args.ntt_log_n)
+        a = h2.to_numpy_u64(h2.gen_scalars_device(3, 1 << args.ntt_log_n, device=dev)).copy()
+        hp["ntt_2p%d_ms" % args.ntt_log_n] = host_ms(lambda: h2.best_fft(a, dk.omega, args.ntt_log_n), reps=3)
+        hp["note"] = "h2hip_msm_bn254 / h2hip_ntt_bn254_fr with host pointers: the scalars (and, unpinned, the bases) cross PCIe inside the call"
+        sizes["host_pointer"] = hp
+        del sc, bs, a
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import trace_bench
+        sizes["trace_k17"] = trace_bench.run(h2, cpu=False)
 
     # ---- SURVEY.md 8(f).3 / (f).4 legs (extra keys; rank 0, N = 1 only), outside the MSM timed region ----
     next_rows = None
-    if rank == 0 and world == 1 and not args.no_next_rows:
+    if solo and not args.no_next_rows:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import evalh_bench
         import g2l_bench
@@ -248,42 +414,77 @@ def main():
     # ---- CPU baseline (rank 0, N = 1 only): the oracle's best_multiexp on the same inputs ----
     cpu = None
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if solo and not args.no_cpu_baseline:
         from oracle import oracle
-        cores = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU
         sc, bs = h2.to_numpy_u64(d_scalars), h2.to_numpy_u64(d_points)
-        oracle.best_multiexp(sc[:4096], bs[:4096], cores)  # warm up
-        times = []
-        cpu_out = None
-        budget = time.perf_counter() + 30.0
-        while len(times) < 5 and time.perf_counter() < budget:
-            t1 = time.perf_counter()
-            cpu_out = oracle.best_multiexp(sc, bs, cores)
-            times.append(time.perf_counter() - t1)
-        tmed = sorted(times)[len(times) // 2]
-        cpu_c = oracle.window_c(n // cores)
+        hw = os.cpu_count() or 1  # rayon uses every hardware thread unless RAYON_NUM_THREADS says otherwise
+        share = min(16, hw)       # the box's CPU share for one GPU
+
+        def cpu_time(threads, budget_s):
+            oracle.best_multiexp(sc[:4096], bs[:4096], threads)  # warm up the thread pool
+            times, out = [], None
+            stop = time.perf_counter() + budget_s
+            while len(times) < 5 and time.perf_counter() < stop:
+                t1 = time.perf_counter()
+                out = oracle.best_multiexp(sc, bs, threads)
+                times.append(time.perf_counter() - t1)
+            return sorted(times)[len(times) // 2], len(times), out
+
+        t_hw, runs_hw, cpu_out = cpu_time(hw, 15.0)
+        cpu_c = oracle.window_c(n // hw)
         cpu = {
-            "value": n * W / tmed,  # same unit as `value`: the job's n*W adds per second of CPU time
+            "value": n * W / t_hw,  # same unit as `value`: the job's n*W adds per second of CPU time
             "unit": "G1-adds/s",
-            "pairs_per_s": n / tmed,
-            "cores": cores,
+            "pairs_per_s": n / t_hw,
+            "cores": hw,
             "cpu_model": cpu_model(),
             "kind": "port",
-            "sample": "full 2^%d-pair MSM, median of %d runs, %.3f s each; C restatement of best_multiexp "
-                      "(chunk = n/T per thread, c = %d unsigned windows), not the Rust binary" % (args.log_n, len(times), tmed, cpu_c),
+            "sample": "full 2^%d-pair MSM, median of %d runs, %.3f s each, T = os.cpu_count() = %d threads; C restatement of best_multiexp "
+                      "(chunk = n/T per thread, c = %d unsigned windows), not the Rust binary" % (args.log_n, runs_hw, t_hw, hw, cpu_c),
         }
+        if share != hw:
+            t_sh, runs_sh, _ = cpu_time(share, 10.0)
+            cpu["share_16_threads"] = {"cores": share, "seconds": t_sh, "pairs_per_s": n / t_sh, "value": n * W / t_sh,
+                                       "note": "the same MSM on the 16 threads that are this GPU's share of the host"}
         parity = bool(np.array_equal(oracle.g1_to_affine(cpu_out), h2.g1_to_affine(result)))
+
+    # ---- N > 1: ONE process driving all N GPUs through the C ABI (h2hip_init with N ids), while the ranks idle ----
+    inlib = None
+    if world > 1 and not args.no_inlib:
+        # The other ranks wait on the host (a marker file; an RCCL barrier would spin on their GPUs, a gloo group prints to
+        # stdout) while rank 0's child process uses all N GPUs.
+        marker = os.path.join(os.environ.get("TMPDIR", "/tmp"), "h2bench_inlib_%s_%s.done" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "x")))
+        if rank == 0:
+            env = dict(os.environ)
+            for k_ in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK"):
+                env.pop(k_, None)
+            if args.backend != "nccl":
+                env["HALO2_HIP_ALLOW_DUPLICATE_DEVICES"] = "1"
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--inlib", str(world), "--log-n", str(args.log_n), "--steps", "7"],
+                                   capture_output=True, text=True, timeout=240, env=env)
+                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("INLIB ")]
+                inlib = json.loads(lines[-1][6:]) if lines else {"error": (r.stdout + r.stderr)[-600:]}
+            except subprocess.TimeoutExpired:
+                inlib = {"error": "timed out after 240 s"}
+            with open(marker, "w") as f:
+                f.write("done")
+        else:
+            stop = time.time() + 300
+            while not os.path.exists(marker) and time.time() < stop:
+                time.sleep(0.05)
+        sync_all()
+        if rank == 0:
+            try:
+                os.remove(marker)
+            except OSError:
+                pass
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         adds = world * n * W * args.steps
         accum_ms = stages.get("msm_accum")
-        roof = None
-        if accum_ms:
-            ach = MSM_BYTES_PER_PAIR * n / (accum_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                    "traffic": pmc_traffic("msm_2p%d" % args.log_n), "kernel": "msm_accum_kernel", "kernel_ms": accum_ms,
-                    "algorithmic_bytes_per_launch": MSM_BYTES_PER_PAIR * n}
+        roof = msm_roofline(n, accum_ms, "msm_2p%d_%s" % (args.log_n, args.form)) if accum_ms else None
         # second roofline, the one that actually binds: 256-bit modular multiplies per second against the
         # multiplier's measured chip-wide peak (tools/mul_rate.hip: 179 G/s for the explicit-mad form at >= 4 waves/SIMD)
         valu = None
@@ -305,16 +506,21 @@ def main():
             "dtype": "u32x8 (256-bit Montgomery integers)",
             "data": "synthetic",
             "config": {"workload": "bn254_g1_msm_2p%d_per_gpu" % args.log_n, "pairs_per_gpu": n, "window_bits": c, "windows": W,
-                       "signed_digits": True, "parallelism": "shard%d+allgather96B" % world},
+                       "signed_digits": True, "form": "fixed-base window table (bases pinned as ParamsKZG pins g / g_lagrange)" if args.form == "fixed"
+                       else "plain (one bucket set per window)", "parallelism": "shard%d+allgather96B" % world},
             "pairs_per_s": world * n * args.steps / elapsed,
             "stage_ms": stages,
+            "pin": pin,
             "roofline": roof,
             "valu_roofline": valu,
             "cpu_baseline": cpu,
             "parity_vs_cpu": parity,
+            "other_form": other_form,
             "batched": batched,
             "ntt": ntt,
+            "sizes": sizes,
             "next_rows": next_rows,
+            "in_library_multi_gpu": inlib,
         }
         print(json.dumps(out))
     if world > 1:

@@ -192,20 +192,79 @@ def bases_pinned_info(bases):
     return n.value, c.value, w.value, b.value
 
 
+# ------------------------------------------------------------------ bn256::Fr constants (halo2curves 0.3.1)
+FR_MODULUS = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+FR_S = 28
+FR_ROOT_OF_UNITY = 0x03ddb9f5166d18b798865ea93dd31f743215cf6dd39329c8d34f1ed960c37c9c
+FR_ZETA = 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23
+_FR_R = (1 << 256) % FR_MODULUS
+
+
+def fr_from_int(v):
+    """integer -> the 4 x u64 Montgomery limbs the reference stores"""
+    m = (int(v) % FR_MODULUS) * _FR_R % FR_MODULUS
+    return np.array([(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def fr_to_int(limbs):
+    m = sum(int(x) << (64 * i) for i, x in enumerate(np.asarray(limbs, dtype=np.uint64).reshape(4)))
+    return m * pow(_FR_R, -1, FR_MODULUS) % FR_MODULUS
+
+
 # ------------------------------------------------------------------ poly/domain.rs
 class EvaluationDomain:
-    """poly::EvaluationDomain<Fr> (poly/domain.rs:18-34): holds the constants `new` computes
-    (:39-142, supplied by the caller -- field inversions are not on the accelerated path) and
-    routes the conversions through the fused device entry points."""
+    """poly::EvaluationDomain<Fr> (poly/domain.rs:18-34): holds the constants `new` computes (:39-142) and routes the
+    conversions through the fused device entry points.  `EvaluationDomain.new(j, k)` computes them here with Python
+    integers (field inversions are not on the accelerated path)."""
 
     FIELDS = ("omega", "omega_inv", "extended_omega", "extended_omega_inv", "g_coset", "g_coset_inv",
               "ifft_divisor", "extended_ifft_divisor")
 
-    def __init__(self, k, extended_k, quotient_poly_degree, **consts):
+    def __init__(self, k, extended_k, quotient_poly_degree, t_evaluations=None, **consts):
         self.k, self.extended_k, self.quotient_poly_degree = int(k), int(extended_k), int(quotient_poly_degree)
         self.n = 1 << self.k
         for f in self.FIELDS:
             setattr(self, f, _fe(consts[f]))
+        self.t_evaluations = None if t_evaluations is None else _u64(t_evaluations, 4)
+
+    @classmethod
+    def new(cls, j, k):
+        """EvaluationDomain::new (poly/domain.rs:39-142)"""
+        r = FR_MODULUS
+        quotient_poly_degree = j - 1                                    # :41
+        n = 1 << k                                                      # :44
+        extended_k = k                                                  # :49-52
+        while (1 << extended_k) < n * quotient_poly_degree:
+            extended_k += 1
+        if extended_k > FR_S:
+            raise ValueError("extended_k exceeds the 2-adicity of Fr")
+        extended_omega = FR_ROOT_OF_UNITY                               # :54-61
+        for _ in range(extended_k, FR_S):
+            extended_omega = extended_omega * extended_omega % r
+        omega = extended_omega                                          # :70-73
+        for _ in range(k, extended_k):
+            omega = omega * omega % r
+        g_coset = FR_ZETA                                               # :81
+        g_coset_inv = g_coset * g_coset % r                             # :82
+        orig = pow(FR_ZETA, n, r)                                       # :84-107
+        step = pow(extended_omega, n, r)
+        t_evaluations, cur = [], orig
+        while True:
+            t_evaluations.append(cur)
+            cur = cur * step % r
+            if cur == orig:
+                break
+        assert len(t_evaluations) == 1 << (extended_k - k)             # :98
+        t_evaluations = [pow((c - 1) % r, -1, r) for c in t_evaluations]   # :101-103, batch_invert :117-124
+        consts = {
+            "omega": omega, "omega_inv": pow(omega, -1, r), "extended_omega": extended_omega,
+            "extended_omega_inv": pow(extended_omega, -1, r), "g_coset": g_coset, "g_coset_inv": g_coset_inv,
+            "ifft_divisor": pow(1 << k, -1, r), "extended_ifft_divisor": pow(1 << extended_k, -1, r),   # :109-110
+        }
+        d = cls(k, extended_k, quotient_poly_degree, t_evaluations=np.stack([fr_from_int(c) for c in t_evaluations]),
+                **{f: fr_from_int(v) for f, v in consts.items()})
+        d.barycentric_weight = fr_from_int(pow(n, -1, r))               # :114
+        return d
 
     def extended_len(self):
         return 1 << self.extended_k
@@ -238,10 +297,10 @@ class EvaluationDomain:
         return a[: self.n * self.quotient_poly_degree]
 
 
-    def divide_by_vanishing_poly(self, a, t_evaluations):
+    def divide_by_vanishing_poly(self, a, t_evaluations=None):
         """poly/domain.rs:307-326"""
         a = _u64(a, 4).copy()
-        t = _u64(t_evaluations, 4)
+        t = self.t_evaluations if t_evaluations is None else _u64(t_evaluations, 4)
         assert a.shape[0] == self.extended_len()
         _check(lib().h2hip_divide_by_vanishing_poly_bn254_fr(_p(a), ctypes.c_uint32(self.extended_k), _p(t), ctypes.c_uint32(t.shape[0])),
                "h2hip_divide_by_vanishing_poly_bn254_fr")

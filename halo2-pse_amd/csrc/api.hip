@@ -936,7 +936,7 @@ static int pin_on_device(Ctx* c, const void* key, const uint64_t* h_points, cons
     pb.device_key = device_key;
     if (sample) memcpy(pb.sample, sample, sizeof(pb.sample));
     uint32_t cw = 0, W = 1;
-    if (g_cfg.fixed_base && n >= 16 && n <= ((size_t)1 << 26)) {
+    if (g_cfg.fixed_base && n <= ((size_t)1 << 26)) {
         cw = msm_table_window(n);
         W = (255 + cw - 1) / cw;
         if ((size_t)W * n * sizeof(Affine) > g_cfg.table_max_bytes) cw = 0, W = 1;

@@ -604,7 +604,7 @@ static uint32_t plain_window(size_t n, bool fused) {
 // reduction costs 2 * 2^(c-1) additions once instead of per window and c follows n
 static uint32_t normalise_window(uint32_t c) {
     if (c < 2) c = 2;
-    if (c > 24) c = 24;
+    if (c > 22) c = 22;  // one bucket set of 2^21 buckets is the most a run sorts (MSM_MAX_C1 << MSM_MAX_L)
     const uint32_t W = (255 + c - 1) / c;
     return (255 + W - 1) / W;
 }

@@ -80,7 +80,7 @@ int h2hip_msm_bn254(const uint64_t* scalars, const uint64_t* bases_xy, size_t n,
  * whose bases pointer equals `bases_xy` (and n' <= n) skip the upload.  For ParamsKZG::{g, g_lagrange}
  * (poly/kzg/commitment.rs:26-27), which live as long as the params; call unpin before the Vec is dropped
  * or mutated (downsize, :267-275).  With several devices each one keeps its contiguous share.
- * Pinning also builds the fixed-base window table 2^(c j) * P_i (j < W = 254/c + 1; 16 <= n <= 2^26; W * n * 64
+ * Pinning also builds the fixed-base window table 2^(pos_j) * P_i (pos_j = first bit of window j, W = ceil(255/c) windows; n <= 2^26; W * n * 64
  * bytes of HBM, e.g. 0.8 GB at 2^20, 12 GB at 2^24): all windows of an MSM then share one bucket set, the
  * windows are wider (c = 20 instead of 16 at 2^20) and no Horner pass is needed.
  * The cache is safe against stale pointers: every lookup compares 16 sampled points of the caller's array

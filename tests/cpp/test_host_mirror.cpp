@@ -2,6 +2,7 @@
 // path (halo2_proofs/src/poly/kzg/commitment.rs:361-384 test_commit_lagrange; poly/domain.rs
 // round trips).  Needs an MI355X.  usage: test_host_mirror <tests/golden dir>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <string>
 
@@ -214,8 +215,30 @@ static void test_evaluate_h_custom_gates() {
     CHECK(panics([&] { ev.evaluate_h(in, short_values); }));
 }
 
+// EvaluationDomain::new(j, k) as hex, one constant per line (no GPU needed): compared with tests/golden by the CPU suite
+static int dump_domain(uint32_t j, uint32_t k) {
+    poly::EvaluationDomain d(j, k);
+    auto hex = [](const char* name, const Fr& f) {
+        std::printf("%s %016llx%016llx%016llx%016llx\n", name, (unsigned long long)f.l[3], (unsigned long long)f.l[2], (unsigned long long)f.l[1],
+                    (unsigned long long)f.l[0]);
+    };
+    std::printf("extended_k %u\n", d.extended_k);
+    hex("omega", d.omega);
+    hex("omega_inv", d.omega_inv);
+    hex("extended_omega", d.extended_omega);
+    hex("extended_omega_inv", d.extended_omega_inv);
+    hex("g_coset", d.g_coset);
+    hex("g_coset_inv", d.g_coset_inv);
+    hex("ifft_divisor", d.ifft_divisor);
+    hex("extended_ifft_divisor", d.extended_ifft_divisor);
+    hex("barycentric_weight", d.barycentric_weight);
+    for (const Fr& t : d.t_evaluations) hex("t_evaluations", t);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc > 2 && std::string(argv[1]) == "--dump-graphs") return dump_graphs(argv[2]);
+    if (argc > 3 && std::string(argv[1]) == "--dump-domain") return dump_domain((uint32_t)std::atoi(argv[2]), (uint32_t)std::atoi(argv[3]));
     std::string dir = argc > 1 ? argv[1] : "tests/golden";
     if (h2hip_init(nullptr, 0) != 0) {
         std::printf("h2hip_init failed: %s\n", h2hip_last_error());

@@ -67,7 +67,7 @@ def test_gpu_downsize_commit_lagrange_identity(h2, oracle):
     params.downsize(k)
     assert params.k == k and params.g.shape[0] == 1 << k and params.g_lagrange.shape[0] == 1 << k
     od, _ = oracle.domain_new(2, k)
-    d = h2.EvaluationDomain(od.k, od.extended_k, od.quotient_poly_degree, **{f: od.fe(f) for f in h2.EvaluationDomain.FIELDS})
+    d = h2.EvaluationDomain.new(od.quotient_poly_degree + 1, od.k)
     a = oracle.gen_scalars(5, 1 << k)
     coeffs = d.lagrange_to_coeff(a)
     lhs = h2.g1_to_affine(params.commit(coeffs))

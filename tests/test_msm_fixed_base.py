@@ -1,0 +1,341 @@
+"""GPU parity tests of the round-2 MSM paths, through the C ABI, bit-exact (after normalising to affine) against the
+CPU oracle and the golden vectors:
+  * the fixed-base form (window tables built by h2hip_bases_pin / h2hip_bases_pin_device), every window width;
+  * the pinned-bases cache's guard against stale host pointers;
+  * fused batches larger than one run (count > 4096 / W windows);
+  * the shape of the reference's own config-5 columns (examples/circuit-layout.rs);
+  * the multi-device engine, rehearsed on one GPU with the same device listed twice.
+Run with `pytest -m gpu` on an MI355X."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+NT = min(16, os.cpu_count() or 1)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _engine(h2):
+    h2.init()
+    yield
+    h2.set_msm_window(0)
+
+
+def aff(h2, xyz):
+    return h2.g1_to_affine(xyz)
+
+
+@pytest.mark.parametrize("case", ["1", "2", "3", "4", "31", "32", "33", "100", "1024", "zeros", "ones", "rm1", "single", "sparse", "cancel"])
+def test_fixed_base_golden(h2, golden, case):
+    sc, bs = golden[f"msm_{case}_scalars"], np.ascontiguousarray(golden[f"msm_{case}_bases"])
+    h2.bases_pin(bs)
+    try:
+        n, c, w, nbytes = h2.bases_pinned_info(bs)
+        assert n == bs.shape[0] and c >= 2 and w == (255 + c - 1) // c and nbytes == w * n * 64
+        assert np.array_equal(aff(h2, h2.best_multiexp(sc, bs)), golden[f"msm_{case}_result"])
+    finally:
+        h2.bases_unpin(bs)
+
+
+@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 13, 16, 17, 20, 22])
+def test_fixed_base_all_window_widths(h2, golden, c):
+    """the table is built with the width in force at pin time; 18, 21 and 24-bit requests normalise to 17, 20, 22"""
+    h2.set_msm_window(c)
+    try:
+        for case in ("33", "1024", "sparse", "rm1"):
+            sc, bs = golden[f"msm_{case}_scalars"], np.ascontiguousarray(golden[f"msm_{case}_bases"])
+            h2.bases_pin(bs)
+            try:
+                assert h2.bases_pinned_info(bs)[1] == c
+                assert np.array_equal(aff(h2, h2.best_multiexp(sc, bs)), golden[f"msm_{case}_result"]), (c, case)
+            finally:
+                h2.bases_unpin(bs)
+    finally:
+        h2.set_msm_window(0)
+
+
+def test_window_requests_are_normalised(h2, golden):
+    sc, bs = golden["msm_1024_scalars"], np.ascontiguousarray(golden["msm_1024_bases"])
+    for asked, used in ((18, 17), (21, 20), (24, 22), (23, 22), (19, 19)):
+        h2.set_msm_window(asked)
+        try:
+            h2.bases_pin(bs)
+            assert h2.bases_pinned_info(bs)[1] == used
+            assert np.array_equal(aff(h2, h2.best_multiexp(sc, bs)), golden["msm_1024_result"])
+            h2.bases_unpin(bs)
+            if asked < 20:  # plain form, same width (wider plain windows need more buckets than one run sorts)
+                assert np.array_equal(aff(h2, h2.best_multiexp(sc, bs)), golden["msm_1024_result"])
+        finally:
+            h2.set_msm_window(0)
+
+
+@pytest.mark.parametrize("n", [1 << 10, (1 << 12) + 37, 1 << 14, 1 << 16])
+def test_fixed_base_vs_oracle_seeded(h2, oracle, n):
+    sc = oracle.gen_scalars(0x5EED0001, n, num_threads=NT)
+    bs = oracle.gen_points(0x5EED0002, n, num_threads=NT)
+    want = oracle.g1_to_affine(oracle.best_multiexp(sc, bs, NT))
+    h2.bases_pin(bs)
+    try:
+        assert h2.bases_pinned_info(bs)[1] > 0
+        assert np.array_equal(aff(h2, h2.best_multiexp(sc, bs)), want)
+        # a shorter polynomial over the same params (commit of a column with fewer coefficients): same table
+        for m in (n // 2, 100, 1):
+            want_m = oracle.g1_to_affine(oracle.best_multiexp(sc[:m], bs[:m], NT))
+            assert np.array_equal(aff(h2, h2.best_multiexp(sc[:m], bs[:m])), want_m), m
+    finally:
+        h2.bases_unpin(bs)
+
+
+def test_fixed_base_skewed_and_degenerate_inputs(h2, oracle):
+    n = 1 << 14
+    bs = oracle.gen_points(77, n, num_threads=NT)
+    one = oracle.fe_from_int(oracle.FR, 1)
+    rng = np.random.default_rng(5)
+    cols = []
+    cols.append(np.repeat(oracle.gen_scalars(78, 1), n, axis=0))        # every scalar equal: one over-full bucket per window
+    sc = oracle.gen_scalars(79, n, num_threads=NT)                        # prover-like: 90 % zero, 5 % in {1, 2}
+    u = rng.random(n)
+    sc[u < 0.90] = 0
+    sc[(u >= 0.90) & (u < 0.95)] = one
+    cols.append(sc)
+    cols.append(np.repeat(one[None, :], n, axis=0))                       # a selector column of ones
+    cols.append(np.zeros((n, 4), dtype=np.uint64))                        # the zero polynomial: identity
+    h2.bases_pin(bs)
+    try:
+        for j, sc in enumerate(cols):
+            want = oracle.g1_to_affine(oracle.best_multiexp(sc, bs, NT))
+            assert np.array_equal(aff(h2, h2.best_multiexp(sc, bs)), want), j
+    finally:
+        h2.bases_unpin(bs)
+    # all bases equal (doublings inside the buckets and the trees), and bases containing the identity
+    bs1 = np.repeat(bs[:1], n, axis=0)
+    bs1[5] = 0
+    h2.bases_pin(bs1)
+    try:
+        want = oracle.g1_to_affine(oracle.best_multiexp(cols[1], bs1, NT))
+        assert np.array_equal(aff(h2, h2.best_multiexp(cols[1], bs1)), want)
+    finally:
+        h2.bases_unpin(bs1)
+
+
+def test_pinned_cache_detects_a_reused_allocation(h2, oracle):
+    """A Vec that is freed and whose address is handed out again must not hit the stale device copy
+    (VERDICT r1 'weak'): the lookup compares 16 sampled points and falls back to uploading."""
+    n = 1 << 12
+    sc = oracle.gen_scalars(5, n, num_threads=NT)
+    bs = oracle.gen_points(6, n, num_threads=NT)
+    other = oracle.gen_points(7, n, num_threads=NT)
+    h2.bases_pin(bs)
+    want_old = oracle.g1_to_affine(oracle.best_multiexp(sc, bs, NT))
+    assert np.array_equal(aff(h2, h2.best_multiexp(sc, bs)), want_old)
+    bs[:] = other  # same address, new contents: what a reused allocation looks like
+    want_new = oracle.g1_to_affine(oracle.best_multiexp(sc, bs, NT))
+    assert np.array_equal(aff(h2, h2.best_multiexp(sc, bs)), want_new)
+    with pytest.raises(h2.H2HipError):  # the stale entry was dropped by the lookup
+        h2.bases_unpin(bs)
+
+
+def test_device_pinned_entry_points(h2, oracle):
+    import torch
+    n = 1 << 13
+    ds = h2.gen_scalars_device(0x5EED0001, n)
+    dp = h2.gen_points_device(0x5EED0002, n)
+    sc, bs = h2.to_numpy_u64(ds), h2.to_numpy_u64(dp)
+    want = oracle.g1_to_affine(oracle.best_multiexp(sc, bs, NT))
+    h2.bases_pin_device(dp)
+    try:
+        info = h2.bases_pinned_info(dp)
+        assert info[0] == n and info[1] > 0
+        assert np.array_equal(aff(h2, h2.msm_device(ds, dp)), want)
+        assert np.array_equal(aff(h2, h2.msm_device(ds, dp, n=1000)), oracle.g1_to_affine(oracle.best_multiexp(sc[:1000], bs[:1000], NT)))
+        cols = [h2.gen_scalars_device(40 + j, n) for j in range(5)]
+        got = h2.msm_batch_device(cols, dp)  # fused, fixed-base: one bucket set per MSM
+        for j, col in enumerate(cols):
+            w = oracle.g1_to_affine(oracle.best_multiexp(h2.to_numpy_u64(col), bs, NT))
+            assert np.array_equal(aff(h2, got[j]), w), j
+        # the copy is the engine's own: overwriting the caller's buffer afterwards changes nothing
+        dp2 = dp.clone()
+        dp.zero_()
+        torch.cuda.synchronize()
+        assert np.array_equal(aff(h2, h2.msm_device(ds, dp)), want)
+        dp.copy_(dp2)
+    finally:
+        h2.bases_unpin_device(dp)
+    assert np.array_equal(aff(h2, h2.msm_device(ds, dp)), want)  # plain form again
+
+
+@pytest.mark.parametrize("n,count", [(1 << 10, 200), (1 << 13, 200)])
+def test_large_batches_split_into_several_fused_runs(h2, oracle, n, count):
+    """count * W windows used to overflow a fixed limit instead of splitting"""
+    dp = h2.gen_points_device(0x5EED0002, n)
+    cols = [h2.gen_scalars_device(1000 + j, n) for j in range(count)]
+    got = h2.msm_batch_device(cols, dp)
+    for j in (0, 1, 57, 113, 157, 158, count - 1):
+        assert np.array_equal(aff(h2, got[j]), aff(h2, h2.msm_device(cols[j], dp))), j
+    bs = h2.to_numpy_u64(dp)
+    w = oracle.g1_to_affine(oracle.best_multiexp(h2.to_numpy_u64(cols[113]), bs, NT))
+    assert np.array_equal(aff(h2, got[113]), w)
+    h2.bases_pin_device(dp)
+    try:
+        got2 = h2.msm_batch_device(cols, dp)
+        for j in range(count):
+            assert np.array_equal(aff(h2, got2[j]), aff(h2, got[j])), j
+    finally:
+        h2.bases_unpin_device(dp)
+
+
+def test_config5_column_shape_k17(h2, oracle):
+    """BASELINE.json configs[4]: the advice columns of examples/circuit-layout.rs at k = 17 hold about twenty assigned
+    rows (examples/circuit-layout.rs:245-265), blinding_factors() + 1 random rows at the end (plonk/prover.rs:350-354)
+    and zeros everywhere else -- 99.98 % zero.  Through the single call, the fused batch and the fixed-base form."""
+    k, n = 17, 1 << 17
+    bs = oracle.gen_points(0x5EED0002, n, num_threads=NT)
+    rng = np.random.default_rng(17)
+    cols = []
+    for j in range(4):
+        col = np.zeros((n, 4), dtype=np.uint64)
+        rows = rng.choice(64, size=20, replace=False)
+        vals = oracle.gen_scalars(300 + j, 20)
+        small = oracle.fe_from_int(oracle.FR, int(rng.integers(1, 5)))
+        vals[::3] = small  # the circuit assigns small constants and products of them
+        col[rows] = vals
+        col[n - 6:] = oracle.gen_scalars(400 + j, 6)  # blinding rows
+        cols.append(col)
+    want = [oracle.g1_to_affine(oracle.best_multiexp(c, bs, NT)) for c in cols]
+    for j, c in enumerate(cols):
+        assert np.array_equal(aff(h2, h2.best_multiexp(c, bs)), want[j]), j
+    got = h2.best_multiexp_batch(cols, bs)
+    for j in range(4):
+        assert np.array_equal(aff(h2, got[j]), want[j]), j
+    h2.bases_pin(bs)
+    try:
+        got = h2.best_multiexp_batch(cols, bs)
+        for j in range(4):
+            assert np.array_equal(aff(h2, got[j]), want[j]), j
+            assert np.array_equal(aff(h2, h2.best_multiexp(cols[j], bs)), want[j]), j
+    finally:
+        h2.bases_unpin(bs)
+
+
+def test_fixed_base_2p20_and_plain_agree(h2, oracle):
+    """BASELINE.json configs[1] through the fixed-base form: bit-exact vs the CPU path at 2^20"""
+    n = 1 << 20
+    ds = h2.gen_scalars_device(0x5EED0001, n)
+    dp = h2.gen_points_device(0x5EED0002, n)
+    plain = aff(h2, h2.msm_device(ds, dp))
+    h2.bases_pin_device(dp)
+    try:
+        assert h2.bases_pinned_info(dp)[1] == h2.get_msm_window_fixed_base(n)
+        fixed = aff(h2, h2.msm_device(ds, dp))
+    finally:
+        h2.bases_unpin_device(dp)
+    assert np.array_equal(plain, fixed)
+    want = oracle.g1_to_affine(oracle.best_multiexp(h2.to_numpy_u64(ds), h2.to_numpy_u64(dp), NT))
+    assert np.array_equal(fixed, want)
+
+
+# ---------------------------------------------------------------------------- several devices behind the C ABI
+_MULTI = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from conftest import load_pkg
+from oracle import oracle
+h2 = load_pkg()
+out = {}
+ndev = h2.device_count()
+out["device_count"] = ndev
+# (1) a device list the box cannot serve is a clean error, not a silent single-GPU run
+try:
+    h2.init([0, ndev])
+    out["bad_list"] = "accepted"
+except h2.H2HipError as e:
+    out["bad_list"] = "rejected: " + str(e)
+# (2) a duplicate is refused unless the rehearsal switch is set
+dup_allowed = os.environ.get("HALO2_HIP_ALLOW_DUPLICATE_DEVICES") == "1"
+try:
+    h2.init([0, 0])
+    out["dup"] = "accepted"
+except h2.H2HipError as e:
+    out["dup"] = "rejected"
+if dup_allowed:
+    assert h2.num_devices() == 2
+    n = 1 << 16
+    sc = oracle.gen_scalars(0x5EED0001, n, num_threads=8)
+    bs = oracle.gen_points(0x5EED0002, n, num_threads=8)
+    want = oracle.g1_to_affine(oracle.best_multiexp(sc, bs, 8)).tolist()
+    out["sharded_equal"] = h2.g1_to_affine(h2.best_multiexp(sc, bs)).tolist() == want
+    out["sharded_odd_equal"] = h2.g1_to_affine(h2.best_multiexp(sc[:n - 3], bs[:n - 3])).tolist() == \
+        oracle.g1_to_affine(oracle.best_multiexp(sc[:n - 3], bs[:n - 3], 8)).tolist()
+    h2.bases_pin(bs)
+    n_p, c, w, nbytes = h2.bases_pinned_info(bs)
+    out["pinned_points"] = n_p
+    out["pinned_equal"] = h2.g1_to_affine(h2.best_multiexp(sc, bs)).tolist() == want
+    m = n // 2 + 11  # ends inside the second device's share
+    out["pinned_prefix_equal"] = h2.g1_to_affine(h2.best_multiexp(sc[:m], bs[:m])).tolist() == \
+        oracle.g1_to_affine(oracle.best_multiexp(sc[:m], bs[:m], 8)).tolist()
+    cols = [oracle.gen_scalars(50 + j, n, num_threads=8) for j in range(3)]
+    got = h2.best_multiexp_batch(cols, bs)
+    out["batch_equal"] = all(h2.g1_to_affine(got[j]).tolist() == oracle.g1_to_affine(oracle.best_multiexp(cols[j], bs, 8)).tolist() for j in range(3))
+    h2.bases_unpin(bs)
+    small = h2.g1_to_affine(h2.best_multiexp(sc[:100], bs[:100])).tolist()  # below the sharding threshold: device 0 only
+    out["small_equal"] = small == oracle.g1_to_affine(oracle.best_multiexp(sc[:100], bs[:100], 8)).tolist()
+    h2.shutdown()
+    h2.init(0)
+    out["after_reinit_equal"] = h2.g1_to_affine(h2.best_multiexp(sc, bs)).tolist() == want
+print("RESULT " + json.dumps(out))
+"""
+
+
+def _run_multi(env_extra):
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, "-c", _MULTI % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):])
+
+
+def test_init_device_list_errors_are_clean():
+    out = _run_multi({"HALO2_HIP_ALLOW_DUPLICATE_DEVICES": "0"})
+    assert out["bad_list"].startswith("rejected") and "out of range" in out["bad_list"]
+    assert out["dup"] == "rejected"
+
+
+def test_two_device_contexts_shard_fold_bit_exact():
+    """h2hip_init with two entries (the same GPU twice: the rehearsal switch) runs the sharded path of h2hip_msm_bn254:
+    one host thread, stream and workspace per context, pinned bases split by range, partials folded -- and gives the
+    single-device result bit for bit.  (RCCL refuses duplicate devices, so the partials meet through host memory
+    here; the ncclAllGather path needs distinct GPUs.)"""
+    out = _run_multi({"HALO2_HIP_ALLOW_DUPLICATE_DEVICES": "1", "HALO2_HIP_MULTI_GPU_MIN_N": "1024"})
+    assert out["dup"] == "accepted"
+    for key in ("sharded_equal", "sharded_odd_equal", "pinned_equal", "pinned_prefix_equal", "batch_equal", "small_equal", "after_reinit_equal"):
+        assert out[key] is True, (key, out)
+    assert out["pinned_points"] == 1 << 16
+
+
+def test_env_device_list_and_thresholds():
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from conftest import load_pkg
+h2 = load_pkg()
+h2.init()
+print("RESULT", h2.num_devices(), h2.msm_min_n(), h2.ntt_min_log_n())
+""" % (ROOT, ROOT)
+    env = dict(os.environ, HALO2_HIP_DEVICES="0", HALO2_HIP_MSM_MIN_N="4096", HALO2_HIP_NTT_MIN_LOGN="12")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1].split()[1:] == ["1", "4096", "12"]
+    env["HALO2_HIP_DEVICES"] = "0,99"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "out of range" in (r.stdout + r.stderr)

@@ -66,7 +66,7 @@ def main():
         ref = None
         for c in args.windows:
             h2.set_msm_window(c)
-            if not args.no_plain and not (c > 21):
+            if not args.no_plain and not (c >= 20):
                 ms, st, r = time_msm(h2, ds, dp, args.reps)
                 aff = h2.g1_to_affine(r)
                 ref = aff if ref is None else ref
