@@ -302,6 +302,32 @@ static bool rccl_load() {
     return true;
 }
 
+// one communicator per engine device (ncclCommInitAll); needs distinct devices.  0 on success.
+static int rccl_comms_create() {
+    if (!g_rccl.comms.empty()) return 0;
+    std::vector<int> ids;
+    for (Ctx* x : g_devs) ids.push_back(x->device);
+    for (size_t i = 0; i < ids.size(); i++)
+        for (size_t j = 0; j < i; j++)
+            if (ids[i] == ids[j]) {
+                set_error("RCCL needs distinct devices (device %d is listed twice); partials are gathered on the host", ids[i]);
+                return H2HIP_EINVAL;
+            }
+    if (!rccl_load()) {
+        set_error("librccl.so.1 not found; partials are gathered on the host");
+        return H2HIP_EDEVICE;
+    }
+    g_rccl.comms.assign(ids.size(), nullptr);
+    ncclResult_t r = g_rccl.CommInitAll(g_rccl.comms.data(), (int)ids.size(), ids.data());
+    (void)hipSetDevice(ids[0]);
+    if (r != ncclSuccess) {
+        set_error("ncclCommInitAll failed (%s); partials are gathered on the host", g_rccl.GetErrorString(r));
+        g_rccl.comms.clear();
+        return H2HIP_EDEVICE;
+    }
+    return 0;
+}
+
 // ---- worker threads: one per secondary device, alive from init to shutdown -------------------------------------------------
 struct Worker {
     std::thread th;
@@ -465,18 +491,7 @@ static int do_init(const int* device_ids, int n_ids) {
         g_workers[i] = new Worker();
         g_workers[i]->th = std::thread(worker_main, g_workers[i], ids[i]);
     }
-    bool distinct = true;
-    for (size_t i = 0; i < ids.size(); i++)
-        for (size_t j = 0; j < i; j++) distinct = distinct && ids[i] != ids[j];
-    if (ids.size() > 1 && g_cfg.gather_rccl && distinct && rccl_load()) {
-        g_rccl.comms.assign(ids.size(), nullptr);
-        ncclResult_t r = g_rccl.CommInitAll(g_rccl.comms.data(), (int)ids.size(), ids.data());
-        if (r != ncclSuccess) {  // not fatal: the host gathers the partials instead
-            set_error("ncclCommInitAll failed (%s); partials are gathered on the host", g_rccl.GetErrorString(r));
-            g_rccl.comms.clear();
-        }
-        (void)hipSetDevice(ids[0]);
-    }
+    if (ids.size() > 1 && g_cfg.gather_rccl) (void)rccl_comms_create();  // not fatal: the host gathers the partials instead
     return 0;
 }
 
@@ -1019,6 +1034,28 @@ int h2hip_bases_unpin(const void* bases_xy) {
         return H2HIP_EINVAL;
     }
     return 0;
+}
+
+// test hook: push `count` Jacobian partials per engine device through the library's RCCL gather (communicators are
+// created on demand, also for a single device) and fold them; out = fold over the devices of partials_xyz[j].
+int h2hip_debug_rccl_gather_selftest(const uint64_t* partials_xyz, size_t count, uint64_t* out_xyz) {
+    if (!partials_xyz || !out_xyz || !count) {
+        set_error("rccl_gather_selftest: null argument");
+        return H2HIP_EINVAL;
+    }
+    Entry en("h2hip_debug_rccl_gather_selftest");
+    if (en.rc) return en.rc;
+    int rc = rccl_comms_create();
+    if (rc) return rc;
+    const int nd = (int)g_devs.size();
+    std::vector<std::vector<XYZZ>> parts((size_t)nd, std::vector<XYZZ>(count));
+    for (int d = 0; d < nd; d++)
+        for (size_t j = 0; j < count; j++) {
+            Jac jc;
+            memcpy(&jc, partials_xyz + 12 * j, 96);
+            parts[(size_t)d][j] = jac_to_xyzz(jc);
+        }
+    return gather_fold(nd, count, parts, out_xyz);
 }
 
 int h2hip_bases_pinned_info(const void* bases_xy, size_t* n_points, uint32_t* window_bits, uint32_t* windows, size_t* device_bytes) {

@@ -293,6 +293,9 @@ int h2hip_profile_get(const char* stage, double* total_ms, uint64_t* count);
 
 /* split MSM inputs above m pairs into consecutive chunks (default 2^26, the 31-bit pair-index limit; 0 restores it) */
 int h2hip_debug_set_msm_max_chunk(size_t m);
+/* push `count` Jacobian partials per engine device through the library's RCCL all-gather (communicators created on
+ * demand, also for one device) and fold them on the host: exercises the multi-GPU gather on any box */
+int h2hip_debug_rccl_gather_selftest(const uint64_t* partials_xyz, size_t count, uint64_t* out_xyz);
 /* buckets with more than (entries of the MSM) / d entries take the chunked path (default d = 32768; 0 restores it) */
 int h2hip_debug_set_msm_heavy_div(size_t d);
 /* target entries per coarse bin of the MSM's two-level sort (default 8192; 0 restores it) */

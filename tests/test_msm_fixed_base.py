@@ -339,3 +339,15 @@ print("RESULT", h2.num_devices(), h2.msm_min_n(), h2.ntt_min_log_n())
     env["HALO2_HIP_DEVICES"] = "0,99"
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and "out of range" in (r.stdout + r.stderr)
+
+
+def test_rccl_gather_path_on_this_box(h2, oracle, golden):
+    """the ncclCommInitAll / ncclAllGather plumbing of the in-library multi-GPU gather, on however many devices the
+    engine holds here (one): the gathered-and-folded partials must come back as the same group elements"""
+    sc, bs = golden["msm_33_scalars"], golden["msm_33_bases"]
+    parts = np.stack([oracle.best_multiexp(sc[:10], bs[:10]), oracle.best_multiexp(sc[10:], bs[10:]), oracle.best_multiexp(sc, bs)])
+    out = np.zeros((3, 12), dtype=np.uint64)
+    rc = h2.lib().h2hip_debug_rccl_gather_selftest(parts.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(3), out.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0, h2.lib().h2hip_last_error().decode()
+    for j in range(3):
+        assert np.array_equal(aff(h2, out[j]), oracle.g1_to_affine(parts[j])), j
