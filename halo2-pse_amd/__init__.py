@@ -322,6 +322,19 @@ class ParamsKZG:
         bases_pin(self.g)
         bases_pin(self.g_lagrange)
 
+    @classmethod
+    def setup(cls, k, secret):
+        """ParamsKZG::setup (poly/kzg/commitment.rs:61-129) with the secret given (an int, or 4 Montgomery limbs) instead
+        of drawn from an rng: g[i] = [s^i] G1, g_lagrange[i] = [l_i(s)] G1, computed on the GPU"""
+        if not 0 <= int(k) <= FR_S:
+            raise H2HipError("kzg_setup: assertion failed: k <= Fr::S")  # :64 (before any allocation of 2^k points)
+        s = fr_from_int(secret) if isinstance(secret, int) else _fe(secret)
+        n = 1 << int(k)
+        g = np.zeros((n, 8), dtype=np.uint64)
+        gl = np.zeros((n, 8), dtype=np.uint64)
+        _check(lib().h2hip_kzg_setup_bn254(ctypes.c_uint32(k), _p(s), _p(g), _p(gl)), "h2hip_kzg_setup_bn254")
+        return cls(k, g, gl)
+
     def commit_lagrange(self, poly, blind=None):
         poly = _u64(poly, 4)
         size = poly.shape[0]

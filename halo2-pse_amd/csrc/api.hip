@@ -630,6 +630,7 @@ static void release_ctx(Ctx* c) {
     c->ecfft_ws.release();
     c->ntt_ptrs.release();
     c->gather.release();
+    c->gen_table.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = nullptr;
     for (auto e : c->aux_events) (void)hipEventDestroy(e);
@@ -1428,6 +1429,38 @@ int h2hip_g_to_lagrange_bn254(const uint64_t* g_xy, uint32_t k, uint64_t* g_lagr
     H2_CHECK(hipMemcpyAsync(d_in, g_xy, bytes, hipMemcpyHostToDevice, c->stream));
     if ((rc = g_to_lagrange_device(c, d_in, k, d_out, c->stream))) return rc;
     H2_CHECK(hipMemcpyAsync(g_lagrange_xy, d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+    H2_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int h2hip_kzg_setup_bn254_device(uint32_t k, const uint64_t secret[4], void* d_g_xy, void* d_g_lagrange_xy, void* stream) {
+    if (!secret || !d_g_xy || !d_g_lagrange_xy) {
+        set_error("kzg_setup: null argument");
+        return H2HIP_EINVAL;
+    }
+    if (check_fr(secret, "secret")) return H2HIP_EINVAL;
+    Entry en("h2hip_kzg_setup_bn254_device", d_g_xy);
+    if (en.rc) return en.rc;
+    return kzg_setup_device(en.c, k, fe_from_u64x4(secret), (Affine*)d_g_xy, (Affine*)d_g_lagrange_xy, (hipStream_t)stream);
+}
+
+int h2hip_kzg_setup_bn254(uint32_t k, const uint64_t secret[4], uint64_t* g_xy, uint64_t* g_lagrange_xy) {
+    if (!secret || !g_xy || !g_lagrange_xy || k > 28) {
+        set_error("kzg_setup: bad argument");
+        return H2HIP_EINVAL;
+    }
+    if (check_fr(secret, "secret")) return H2HIP_EINVAL;
+    Entry en("h2hip_kzg_setup_bn254");
+    if (en.rc) return en.rc;
+    Ctx* c = en.c;
+    const size_t bytes = sizeof(Affine) << k;
+    int rc = c->ntt_io.ensure(2 * bytes);
+    if (rc) return rc;
+    Affine* d_g = (Affine*)c->ntt_io.p;
+    Affine* d_gl = (Affine*)((char*)c->ntt_io.p + bytes);
+    if ((rc = kzg_setup_device(c, k, fe_from_u64x4(secret), d_g, d_gl, c->stream))) return rc;
+    H2_CHECK(hipMemcpyAsync(g_xy, d_g, bytes, hipMemcpyDeviceToHost, c->stream));
+    H2_CHECK(hipMemcpyAsync(g_lagrange_xy, d_gl, bytes, hipMemcpyDeviceToHost, c->stream));
     H2_CHECK(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -91,7 +91,7 @@ struct Ctx {
     bool ready = false;
     hipStream_t stream = nullptr;  // the engine's own stream (host-pointer entry points)
     std::recursive_mutex mu;       // serialises entry points: re-entrant callers (rayon workers) are safe
-    DevBuf ntt_ws, ntt_io, msm_scalars[3], msm_bases, msm_slot[3], misc, evalh_ws, evalh_slots, ecfft_ws, ntt_ptrs, gather;
+    DevBuf ntt_ws, ntt_io, msm_scalars[3], msm_bases, msm_slot[3], misc, evalh_ws, evalh_slots, ecfft_ws, ntt_ptrs, gather, gen_table;
     HostBuf host_ws;               // pinned host memory for the window sums coming back
     // Small host tables the kernels read (pointer lists, constants) go through this pinned ring, so that the
     // asynchronous copy never reads a caller's stack or a std::vector that is gone by the time the DMA runs.
@@ -148,6 +148,9 @@ int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const uint64_t* h_t, uint
 // ecfft.hip
 int g_to_lagrange_device(Ctx* c, const Affine* d_g, uint32_t k, Affine* d_out, hipStream_t s);
 int ec_normalize_device(const XYZZ* d_in, Affine* d_out, uint64_t n, hipStream_t s);  // batched XYZZ -> affine
+
+// setup.hip
+int kzg_setup_device(Ctx* c, uint32_t k, const Fe& s, Affine* d_g, Affine* d_gl, hipStream_t stream);
 
 // evalh.hip
 void evalh_debug_set_max_local_slots(uint32_t v);

@@ -827,7 +827,10 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         set_error("evaluate_h: metadata region overflow");
         return 1;
     }
-    if (!mb.host.empty()) H2_CHECK(hipMemcpyAsync(mb.dev_base, mb.host.data(), mb.host.size(), hipMemcpyHostToDevice, s));
+    if (!mb.host.empty()) {  // through the pinned ring (or a synchronous copy when large): mb.host dies with this frame
+        int rc_up = c->stage_h2d(mb.dev_base, mb.host.data(), mb.host.size(), s);
+        if (rc_up) return rc_up;
+    }
     // ---- columns: host -> device copies (host-pointer form), then advice / instance polynomials -> extended cosets
     //      (:306-323) in one batched transform: distribute_powers_zeta(into_coset) + zero-pad + NTT, as h2hip_coeff_to_extended does
     for (const Upload& u : uploads) H2_CHECK(hipMemcpyAsync(u.dst, u.src, u.elems * sizeof(Fe), hipMemcpyHostToDevice, s));

@@ -99,6 +99,7 @@ struct L1Args {
     uint32_t n, c, q, W, cb, L, C1;
     uint32_t shared, stride;  // fixed-base: entry index = window * stride + pair
     uint32_t tile;                // scalars per workgroup of the scatter pass
+    uint32_t count_tile;          // scalars per workgroup of the count pass (multiple of 256)
     uint32_t* g_cnt;              // [C1] coarse-bin sizes (count pass)
     const uint32_t* coarse_start; // [C1 + 1] (scatter pass)
     uint32_t* g_cursor;           // [C1] entries already reserved per coarse bin (scatter pass)
@@ -121,8 +122,8 @@ __global__ void __launch_bounds__(256) msm_l1_count_kernel(L1Args a) {
     __syncthreads();
     const Fe* __restrict__ scalars = a.list ? a.list[blockIdx.y] : a.scalars_one;
     const uint32_t set0 = a.shared ? blockIdx.y : blockIdx.y * a.W;
-    const uint32_t i0 = blockIdx.x * MSM_COUNT_TILE + threadIdx.x;
-    for (uint32_t t = 0; t < MSM_COUNT_TILE / 256; t++) {
+    const uint32_t i0 = blockIdx.x * a.count_tile + threadIdx.x;
+    for (uint32_t t = 0; t < a.count_tile / 256; t++) {
         const uint32_t i = i0 + t * 256;
         if (i < a.n) {
             const Fe sc = fr_to_canonical(scalars[i]);
@@ -502,11 +503,19 @@ __global__ void __launch_bounds__(256) msm_rowcol_kernel(RowColArgs args) {
     if (live) {
         const uint32_t a = task / per_arr, idx = task - a * per_arr;
         const XYZZu* X = J.in + ((size_t)a << (J.log_rows + J.log_cols));
-        if (!J.cols_kind) {
-            const XYZZu* row = X + ((size_t)idx << J.log_cols);
-            for (uint32_t l = g; l < cols; l += G) xyzzu_add(acc, row[l]);
-        } else {
-            for (uint32_t h = g; h < rows; h += G) xyzzu_add(acc, X[((size_t)h << J.log_cols) + idx]);
+        // element i of this lane's sum sits at first + i * step; the next one is fetched before the current addition
+        const XYZZu* first = J.cols_kind ? X + idx + ((size_t)g << J.log_cols) : X + ((size_t)idx << J.log_cols) + g;
+        const size_t step = J.cols_kind ? ((size_t)G << J.log_cols) : (size_t)G;
+        const uint32_t terms = J.cols_kind ? rows : cols;
+        if (g < terms) {
+            XYZZu cur = first[0];
+            for (uint32_t i = g + G; i < terms; i += G) {
+                first += step;
+                const XYZZu nxt = first[0];
+                xyzzu_add(acc, cur);
+                cur = nxt;
+            }
+            xyzzu_add(acc, cur);
         }
     }
     sh[threadIdx.x] = acc;
@@ -794,7 +803,10 @@ static int msm_stage_a(Ctx* c, const MsmLayout& L, char* base, const Fe* const* 
     a.coarse_start = cstart;
     a.g_cursor = ccur;
     a.tmp = (uint2*)(base + L.o_tmp);
-    hipLaunchKernelGGL(msm_l1_count_kernel, dim3((uint32_t)((n + MSM_COUNT_TILE - 1) / MSM_COUNT_TILE), L.fuse), dim3(256), 0, s, a);
+    // one non-returning global atomic per (workgroup, bin): large tiles where there are many workgroups anyway, small
+    // ones where the pass would otherwise be a handful of workgroups walking 16 scalars per lane
+    a.count_tile = n * L.fuse >= ((size_t)1 << 22) ? MSM_COUNT_TILE : 1024;
+    hipLaunchKernelGGL(msm_l1_count_kernel, dim3((uint32_t)((n + a.count_tile - 1) / a.count_tile), L.fuse), dim3(256), 0, s, a);
     H2_CHECK(hipGetLastError());
     c->timer_end(t0, s);
     int t1 = c->timer_begin("msm_sort", s);

@@ -348,7 +348,7 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
             h[count + i] = h_firsts[i];
             h[2 * count + i] = ws ? ws + (i << log_n) : nullptr;
         }
-        H2_CHECK(hipMemcpyAsync(c->ntt_ptrs.p, h.data(), h.size() * sizeof(void*), hipMemcpyHostToDevice, s));  // pageable: staged before return
+        if ((rc = c->stage_h2d(c->ntt_ptrs.p, h.data(), h.size() * sizeof(void*), s))) return rc;  // through the pinned ring: `h` dies with this frame
         l_data = (Fe* const*)c->ntt_ptrs.p;
         l_first = (const Fe* const*)c->ntt_ptrs.p + count;
         l_ws = (Fe* const*)c->ntt_ptrs.p + 2 * count;

@@ -230,6 +230,26 @@ class ParamsKZG {
     ParamsKZG& operator=(const ParamsKZG&) = delete;
     ~ParamsKZG() { unpin(); }
 
+    // setup (poly/kzg/commitment.rs:61-129) with the secret supplied: the reference draws `s` from its rng argument
+    // (:72, "MUST NOT be used in production"); everything after that line is what runs here, on the GPU.
+    // g2 / s_g2 (:118-119) are the verifier's half and stay zero.
+    static void setup(uint32_t k, const Fr& s, ParamsKZG& p) {
+        if (k > Fr::S) throw std::logic_error("assertion failed: k <= E::Scalar::S");  // :64
+        p.unpin();
+        p.k = k;
+        p.n = uint64_t(1) << k;
+        p.g.resize(p.n);
+        p.g_lagrange.resize(p.n);
+        engine_check(h2hip_kzg_setup_bn254(k, s.l, p.g[0].x, p.g_lagrange[0].x), "h2hip_kzg_setup_bn254");
+        p.pin();
+    }
+    // the reference's signature: `rng` is any callable returning an Fr (<E::Scalar>::random(rng), :72)
+    template <class Rng>
+    static void setup(uint32_t k, Rng&& rng, ParamsKZG& p) {
+        const Fr s = rng();
+        setup(k, s, p);
+    }
+
     // SerdeFormat (helpers.rs:8-21); `Processed` (compressed points) is not on this path
     enum class SerdeFormat { RawBytes, RawBytesUnchecked };
 

@@ -186,6 +186,13 @@ int h2hip_coeff_to_extended_bn254_fr_batch_device(void* const* d_a, size_t count
 int h2hip_g_to_lagrange_bn254(const uint64_t* g_xy, uint32_t k, uint64_t* g_lagrange_xy);
 int h2hip_g_to_lagrange_bn254_device(const void* d_g_xy, uint32_t k, void* d_g_lagrange_xy, void* stream);
 
+/* ---- ParamsKZG::setup: poly/kzg/commitment.rs:61-129, with the secret supplied by the caller (the reference draws it from
+ * an rng at :72): g[i] = [s^i] G1 and g_lagrange[i] = [l_i(s)] G1 for i < 2^k, affine, as batch_normalize leaves them.
+ * k <= 28; a secret that is a 2^k-th root of unity is H2HIP_EINVAL (the reference panics on the inversion at :100).
+ * The G2 half of the parameters (g2, s_g2: :118-119) belongs to the verifier and is not produced here. */
+int h2hip_kzg_setup_bn254(uint32_t k, const uint64_t secret[4], uint64_t* g_xy, uint64_t* g_lagrange_xy);
+int h2hip_kzg_setup_bn254_device(uint32_t k, const uint64_t secret[4], void* d_g_xy, void* d_g_lagrange_xy, void* stream);
+
 /* ---- Evaluator::evaluate_h: plonk/evaluation.rs:280-522 ---------------------------------------
  * The quotient numerator h(X) on the extended coset: per row, the custom-gate graph (GraphEvaluator, :191-201,
  * :708-749), the permutation argument's constraints (:362-441) and every lookup's constraints (:443-518), folded
@@ -284,7 +291,7 @@ int h2hip_set_msm_window(uint32_t c);
 uint32_t h2hip_get_msm_window(size_t n);
 uint32_t h2hip_get_msm_window_fixed_base(size_t n);
 /* Per-stage HIP-event timers recorded on the stream each kernel group is launched on.
- * Stages: "ntt", "msm_total", "msm_digits", "msm_sort", "msm_accum", "msm_heavy", "msm_reduce", "g_to_lagrange". */
+ * Stages: "ntt", "msm_total", "msm_digits", "msm_sort", "msm_accum", "msm_heavy", "msm_reduce", "g_to_lagrange", "kzg_setup". */
 int h2hip_profile_enable(int on);
 int h2hip_profile_reset(void);
 int h2hip_profile_get(const char* stage, double* total_ms, uint64_t* count);

@@ -88,3 +88,44 @@ def test_g_to_lagrange_rejects_bad_arguments(h2):
     assert b"g_to_lagrange" in L.h2hip_last_error()
     with pytest.raises(AssertionError):
         h2.g_to_lagrange(np.zeros((3, 8), dtype=np.uint64), 2)           # a.len() == 1 << log_n (arithmetic.rs:184)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [3, 6])
+def test_kzg_setup_golden(h2, golden, k):
+    """ParamsKZG::setup (poly/kzg/commitment.rs:61-129) on the GPU against the textbook SRS minted with Python integers"""
+    h2.init()
+    params = h2.ParamsKZG.setup(k, golden[f"kzg_{k}_secret"])
+    try:
+        assert np.array_equal(params.g, golden[f"kzg_{k}_g"])
+        assert np.array_equal(params.g_lagrange, golden[f"kzg_{k}_g_lagrange"])
+        # the reference's own identity (:361-384) over the fresh parameters
+        got = h2.g1_to_affine(params.commit_lagrange(golden[f"kzg_{k}_poly_lagrange"]))
+        assert np.array_equal(got, golden[f"kzg_{k}_commit_lagrange"])
+    finally:
+        params.close()
+
+
+@pytest.mark.gpu
+def test_kzg_setup_vs_oracle_and_contract(h2, oracle):
+    h2.init()
+    for k, seed in ((0, 11), (1, 12), (9, 13)):
+        s = oracle.gen_scalars(seed, 1)[0]
+        g, gl = oracle.kzg_setup(k, s)
+        params = h2.ParamsKZG.setup(k, s)
+        try:
+            assert np.array_equal(params.g, g) and np.array_equal(params.g_lagrange, gl), k
+        finally:
+            params.close()
+    # g_lagrange from setup equals g_to_lagrange(g) (what downsize recomputes, :274)
+    s = oracle.gen_scalars(14, 1)[0]
+    params = h2.ParamsKZG.setup(7, s)
+    try:
+        assert np.array_equal(h2.g_to_lagrange(params.g, 7), params.g_lagrange)
+    finally:
+        params.close()
+    # a secret that is an n-th root of unity makes the reference panic at the inversion (:100): an error here
+    with pytest.raises(h2.H2HipError):
+        h2.ParamsKZG.setup(4, 1)
+    with pytest.raises(h2.H2HipError):
+        h2.ParamsKZG.setup(29, 5)
