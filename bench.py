@@ -167,9 +167,15 @@ def main():
     ap.add_argument("--no-sizes", action="store_true", help="skip the other sizes (2^22..2^26 MSM, 2^20..2^26 NTT, host-pointer figures, k = 17 trace)")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the evaluate_h / g_to_lagrange legs (SURVEY.md 8(f).3, (f).4)")
     ap.add_argument("--no-inlib", action="store_true", help="N > 1: skip the single-process N-device leg (h2hip_init with N ids)")
+    ap.add_argument("--only-step", action="store_true", help="nothing but the timed step (counter passes: one kernel mix per run)")
+    ap.add_argument("--only-ntt", action="store_true", help="nothing but the NTT leg (counter passes)")
     ap.add_argument("--inlib", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.only_step or args.only_ntt:
+        args.no_cpu_baseline = args.no_sizes = args.no_next_rows = args.no_inlib = True
+        args.batch = 0
+        args.no_ntt = args.only_step
     if args.inlib:
         return inlib_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -228,6 +234,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.only_ntt:
+        args.steps, args.warmup = 1, 0
     for _ in range(args.warmup):
         result = step()
     h2.profile_enable(True)
@@ -253,7 +261,7 @@ def main():
 
     # ---- the other form of the same MSM (plain when the step is fixed-base and vice versa), rank 0, N = 1 ----
     other_form = None
-    if solo:
+    if solo and not (args.only_step or args.only_ntt):
         if args.form == "fixed":
             h2.bases_unpin_device(d_points)
         else:

@@ -58,6 +58,10 @@ def lib():
         L.h2hip_get_msm_window_fixed_base.argtypes = [ctypes.c_size_t]
         L.h2hip_msm_min_n.restype = ctypes.c_size_t
         L.h2hip_ntt_min_log_n.restype = ctypes.c_uint32
+        # release streams, workspaces and worker threads while the HIP runtime is still alive (a profiler's own
+        # finalisation otherwise meets them in the static destructors at process exit)
+        import atexit
+        atexit.register(L.h2hip_shutdown)
         _lib = L
     return _lib
 
