@@ -509,7 +509,8 @@ def ntt_min_log_n():
 
 
 def profile_enable(on=True):
-    _check(lib().h2hip_profile_enable(1 if on else 0), "h2hip_profile_enable")
+    """True / 1: every stage; 2: only the dominant kernel, through its own dispatch (no gaps); False / 0: off"""
+    _check(lib().h2hip_profile_enable(int(on)), "h2hip_profile_enable")
 
 
 def profile_reset():

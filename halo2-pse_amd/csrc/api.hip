@@ -21,7 +21,7 @@ void msm_set_window(uint32_t c);
 void msm_set_max_chunk(size_t m);
 void msm_set_heavy_div(size_t d);
 void msm_set_bin_entries(size_t d);
-void msm_set_l1_mode(int m);
+void msm_set_bucket_order(int local);
 void ntt_set_smax(uint32_t v);
 void msm_set_reserved_cus(uint32_t k);
 uint32_t msm_get_reserved_cus();
@@ -128,6 +128,18 @@ int Ctx::timer_begin(const char* name, hipStream_t s) {
     (void)hipEventRecord(t.e0, s);
     t.pending = true;
     timers.push_back(t);
+    return (int)timers.size() - 1;
+}
+
+int Ctx::timer_kernel(const char* name, hipEvent_t* e0, hipEvent_t* e1) {
+    if (!profiling_kernel || profiling) return -1;
+    StageTimer t;
+    t.name = name;
+    if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess) return -1;
+    t.pending = true;
+    timers.push_back(t);
+    *e0 = t.e0;
+    *e1 = t.e1;
     return (int)timers.size() - 1;
 }
 
@@ -1531,8 +1543,9 @@ int h2hip_debug_set_msm_heavy_div(size_t d) {
     return 0;
 }
 
-int h2hip_debug_set_msm_l1_mode(int m) {
-    msm_set_l1_mode(m);
+// tuning hook: 1 = order the buckets by size inside each sort bin only (no global pass); 0 = global order (default)
+int h2hip_debug_set_msm_bucket_order(int local) {
+    msm_set_bucket_order(local);
     return 0;
 }
 
@@ -1573,7 +1586,8 @@ int h2hip_debug_set_reserved_cus(uint32_t k) {
 int h2hip_profile_enable(int on) {
     Ctx* c = ctx();
     std::lock_guard<std::recursive_mutex> lk(c->mu);
-    c->profiling = on != 0;
+    c->profiling = on == 1;
+    c->profiling_kernel = on == 2;
     return 0;
 }
 

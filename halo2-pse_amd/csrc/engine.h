@@ -101,10 +101,12 @@ struct Ctx {
     std::map<TwiddleKey, TwiddleTable> twiddles;
     std::map<const void*, PinnedBases> pinned;
     // profiling
-    bool profiling = false;
+    bool profiling = false;        // every stage bracketed by a pair of events (each record costs the stream ~10 us)
+    bool profiling_kernel = false; // only the dominant kernel, timed through its own dispatch (hipExtLaunchKernelGGL): no gap
     std::vector<StageTimer> timers;
     int timer_begin(const char* name, hipStream_t s);
     void timer_end(int id, hipStream_t s);
+    int timer_kernel(const char* name, hipEvent_t* e0, hipEvent_t* e1);  // events for hipExtLaunchKernelGGL; -1: not profiling
     void timers_collect();
     int sm_count = 256;
     // The workspaces above are shared by every call.  Calls are serialised on the host by `mu`, but

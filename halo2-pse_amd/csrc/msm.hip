@@ -32,6 +32,7 @@
 //                              row sums R and column sums C; applied twice, then
 //      msm_final_kernel        <= 256 small multiples + one tree per bucket set
 //   D  host                    plain form only: Horner over the W set sums with c doublings each
+#include <hip/hip_ext.h>
 #include <string.h>
 
 #include <vector>
@@ -577,8 +578,8 @@ static uint32_t g_window_override = 0;
 static size_t g_heavy_div = 32768;
 static size_t g_bin_entries = 8192;
 static uint32_t g_accum_bs = 256;
-static bool g_global_order = true;
-void msm_set_l1_mode(int m) { g_global_order = m == 0; }
+static bool g_global_order = true;  // false: bucket order local to a sort bin (measured 1.3-1.8x slower accumulation)
+void msm_set_bucket_order(int local) { g_global_order = local == 0; }
 void msm_set_bin_entries(size_t d) { g_bin_entries = d ? d : 8192; }
 void msm_set_heavy_div(size_t d) { g_heavy_div = d ? d : 32768; }
 static size_t g_max_chunk = (size_t)1 << 26;
@@ -621,11 +622,10 @@ static uint32_t normalise_window(uint32_t c) {
 uint32_t msm_table_window(size_t n) {
     if (g_window_override) return normalise_window(g_window_override);
     const uint32_t lg = floor_log2(n);
-    uint32_t c;
-    if (lg <= 10) c = lg < 4 ? 4 : lg;
-    else if (lg <= 19) c = lg;
-    else if (lg <= 22) c = 20;
-    else c = 22;
+    // swept on MI355X (tools/msm_bench.py --windows): up to 2^17 points c = 17 (a lone MSM would take c = 20 -- 0.70 instead
+    // of 0.78 ms at 2^17 -- but the prover's fused batches pay the 2 * 2^(c-1) additions of the reduction once per MSM:
+    // 0.19 ms per MSM of a 16 x 2^17 batch at c = 17); 2^18..2^22: c = 20; beyond: c = 22
+    uint32_t c = lg <= 12 ? 13 : lg <= 17 ? 17 : lg <= 22 ? 20 : 22;  // up to 2^12 points the MSM is all reduction tail: few buckets
     return normalise_window(c);
 }
 
@@ -646,6 +646,8 @@ static MsmPlan make_plan(size_t n, bool fused, const MsmTable* tab) {
     // (e.g. the few buckets of a narrow top window) sets the kernel's duration.
     size_t t = (n * p.W) / g_heavy_div;
     if (t < 32) t = 32;
+    const size_t mean = (p.shared ? n * p.W : n) >> p.cb;  // few buckets (narrow windows): the ordinary bucket is not "over-full"
+    if (t < 4 * mean) t = 4 * mean;
     p.heavy_t = (uint32_t)t;
     p.chunk = 4096;
     return p;
@@ -837,8 +839,13 @@ static int msm_stage_b(Ctx* c, const MsmLayout& L, char* base, const Affine* d_p
     HeavyChunk* hc = (HeavyChunk*)(base + L.o_hc);
     XYZZu* hs = (XYZZu*)(base + L.o_hs);
     int t2 = c->timer_begin("msm_accum", s);
-    hipLaunchKernelGGL(msm_accum_kernel, dim3((L.K + g_accum_bs - 1) / g_accum_bs), dim3(g_accum_bs), 0, s, d_points, vals, start, counts, perm, L.K,
-                       p.heavy_t, p.chunk, buckets, hcnt, hb, hc);
+    hipEvent_t ke0 = nullptr, ke1 = nullptr;
+    if (c->timer_kernel("msm_accum", &ke0, &ke1) >= 0)  // the dispatch's own begin / end timestamps: no marker packets around it
+        hipExtLaunchKernelGGL(msm_accum_kernel, dim3((L.K + g_accum_bs - 1) / g_accum_bs), dim3(g_accum_bs), 0, s, ke0, ke1, 0, d_points, vals, start,
+                              counts, perm, L.K, p.heavy_t, p.chunk, buckets, hcnt, hb, hc);
+    else
+        hipLaunchKernelGGL(msm_accum_kernel, dim3((L.K + g_accum_bs - 1) / g_accum_bs), dim3(g_accum_bs), 0, s, d_points, vals, start, counts, perm,
+                           L.K, p.heavy_t, p.chunk, buckets, hcnt, hb, hc);
     H2_CHECK(hipGetLastError());
     c->timer_end(t2, s);
     int t3 = c->timer_begin("msm_heavy", s);

@@ -292,6 +292,8 @@ uint32_t h2hip_get_msm_window(size_t n);
 uint32_t h2hip_get_msm_window_fixed_base(size_t n);
 /* Per-stage HIP-event timers recorded on the stream each kernel group is launched on.
  * Stages: "ntt", "msm_total", "msm_digits", "msm_sort", "msm_accum", "msm_heavy", "msm_reduce", "g_to_lagrange", "kzg_setup". */
+/* on = 1: every stage (each event record costs the stream ~10 us of gap); on = 2: only the dominant kernel ("msm_accum"),
+ * timed through its own dispatch packet with no gap; 0: off */
 int h2hip_profile_enable(int on);
 int h2hip_profile_reset(void);
 int h2hip_profile_get(const char* stage, double* total_ms, uint64_t* count);
@@ -305,7 +307,9 @@ int h2hip_debug_set_msm_max_chunk(size_t m);
 int h2hip_debug_rccl_gather_selftest(const uint64_t* partials_xyz, size_t count, uint64_t* out_xyz);
 /* buckets with more than (entries of the MSM) / d entries take the chunked path (default d = 32768; 0 restores it) */
 int h2hip_debug_set_msm_heavy_div(size_t d);
-/* target entries per coarse bin of the MSM's two-level sort (default 8192; 0 restores it) */
+/* 1: accumulate order = buckets by size inside each sort bin only; 0 (default): global size order */
+int h2hip_debug_set_msm_bucket_order(int local);
+/* target entries per coarse bin of the MSM's two-level sort (default 16384 = one LDS tile; 0 restores it) */
 int h2hip_debug_set_msm_bin_entries(size_t d);
 /* CUs reserved for the sort / reduce streams of a batched MSM (0 = none: every split measured slower) */
 int h2hip_debug_set_reserved_cus(uint32_t k);
