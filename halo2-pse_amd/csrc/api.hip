@@ -22,6 +22,7 @@ void msm_set_max_chunk(size_t m);
 void msm_set_heavy_div(size_t d);
 void msm_set_bin_entries(size_t d);
 void msm_set_bucket_order(int local);
+void msm_set_quad_tail(bool on);
 void ntt_set_smax(uint32_t v);
 void msm_set_reserved_cus(uint32_t k);
 uint32_t msm_get_reserved_cus();
@@ -1540,6 +1541,12 @@ int h2hip_debug_set_msm_max_chunk(size_t m) {
 // tuning hook: buckets above (entries of the MSM) / d go to the chunked path (default 32768; 0 restores it)
 int h2hip_debug_set_msm_heavy_div(size_t d) {
     msm_set_heavy_div(d);
+    return 0;
+}
+
+// tuning hook: the reduction tail with one quad of lanes per group operation (1, default) or one lane (0)
+int h2hip_debug_set_msm_quad_tail(int on) {
+    msm_set_quad_tail(on != 0);
     return 0;
 }
 

@@ -37,6 +37,7 @@
 
 #include <vector>
 
+#include "ecq.cuh"
 #include "engine.h"
 #include "host64.h"
 
@@ -560,6 +561,110 @@ __global__ void __launch_bounds__(256) msm_final_kernel(FinalArgs args, XYZZ* __
     if (threadIdx.x == 0) set_sums[set] = xyzzu_to_ext(r);  // canonical E-form
 }
 
+// ---- the same two kernels with one QUAD of lanes per group operation (ecq.cuh), for runs with few bucket sets, whose
+// ---- reduction tail is a latency chain on a handful of waves.  Workgroups are single waves so that the chains spread
+// ---- over the chip's SIMDs instead of sharing one CU's issue slots.
+
+// row / column sums, 16 quads per workgroup, 2^g_log quads per sum
+__global__ void __launch_bounds__(64) msm_rowcol_quad_kernel(RowColArgs args) {
+    __shared__ XYZZu sh[16];
+    uint32_t ji = 0;
+    for (uint32_t q = 1; q < args.n_jobs; q++)
+        if (blockIdx.x >= args.job[q].first_block) ji = q;
+    const RowColJob& J = args.job[ji];
+    const uint32_t quad = threadIdx.x >> 2, role = threadIdx.x & 3;
+    const uint32_t G = 1u << J.g_log, g = quad & (G - 1);
+    const uint32_t rows = 1u << J.log_rows, cols = 1u << J.log_cols;
+    const uint32_t per_arr = J.cols_kind ? cols : rows;
+    const uint32_t task = (blockIdx.x - J.first_block) * (16u >> J.g_log) + (quad >> J.g_log);
+    const bool live = task < J.n_arr * per_arr;
+    XYZZu acc = xyzzu_identity();
+    if (live) {
+        const uint32_t a = task / per_arr, idx = task - a * per_arr;
+        const XYZZu* X = J.in + ((size_t)a << (J.log_rows + J.log_cols));
+        const XYZZu* first = J.cols_kind ? X + idx + ((size_t)g << J.log_cols) : X + ((size_t)idx << J.log_cols) + g;
+        const size_t step = J.cols_kind ? ((size_t)G << J.log_cols) : (size_t)G;
+        const uint32_t terms = J.cols_kind ? rows : cols;
+        for (uint32_t i = g; i < terms; i += G) {
+            xyzzu_add_q(acc, first[0], role);
+            first += step;
+        }
+    }
+    if (role == 0) sh[quad] = acc;
+    __syncthreads();
+    for (uint32_t stride = G >> 1; stride >= 1; stride >>= 1) {
+        if (g < stride) {
+            XYZZu x = sh[quad];
+            xyzzu_add_q(x, sh[quad + stride], role);
+            if (role == 0) sh[quad] = x;
+        }
+        __syncthreads();
+    }
+    if (live && g == 0 && role == 0) J.out[task] = sh[quad];
+}
+
+// final, part 1: workgroup (set, group) scales 16 of the set's remaining points (one per quad) and sums them
+__global__ void __launch_bounds__(64) msm_final_quad_kernel(FinalArgs args, uint32_t n_groups, XYZZu* __restrict__ partials) {
+    __shared__ XYZZu sh[16];
+    const uint32_t set = blockIdx.x / n_groups, group = blockIdx.x - set * n_groups;
+    const uint32_t quad = threadIdx.x >> 2, role = threadIdx.x & 3;
+    uint32_t e = group * 16 + quad;  // index into the set's arrays laid end to end
+    // locate the array with selects (a run-time index into the kernel argument would go through scratch)
+    const XYZZu* base = nullptr;
+    uint32_t stride = 0, o = 0, k = 0, nbits = 0;
+    bool found = false;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+        if (i < args.n_arr && !found) {
+            if (e < args.arr[i].len) {
+                found = true;
+                base = args.arr[i].base;
+                stride = args.arr[i].stride;
+                o = args.arr[i].o;
+                k = args.arr[i].k;
+                nbits = args.arr[i].nbits;
+            } else {
+                e -= args.arr[i].len;
+            }
+        }
+    }
+    XYZZu x = xyzzu_identity();
+    if (found) {
+        const uint32_t wgt = (e + o) << k;
+        if (wgt) x = xyzzu_mul_small_q(base[(size_t)set * stride + e], wgt, nbits, role);
+    }
+    if (role == 0) sh[quad] = x;
+    __syncthreads();
+    for (uint32_t st = 8; st >= 1; st >>= 1) {
+        if (quad < st) {
+            XYZZu a = sh[quad];
+            xyzzu_add_q(a, sh[quad + st], role);
+            if (role == 0) sh[quad] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
+}
+
+// final, part 2: one wave per set sums the <= 16 partials
+__global__ void __launch_bounds__(64) msm_final_sum_kernel(const XYZZu* __restrict__ partials, uint32_t n_groups, XYZZ* __restrict__ set_sums) {
+    __shared__ XYZZu sh[16];
+    const uint32_t quad = threadIdx.x >> 2, role = threadIdx.x & 3;
+    XYZZu x = xyzzu_identity();
+    if (quad < n_groups) x = partials[(size_t)blockIdx.x * n_groups + quad];
+    if (role == 0) sh[quad] = x;
+    __syncthreads();
+    for (uint32_t st = 8; st >= 1; st >>= 1) {
+        if (quad < st) {
+            XYZZu a = sh[quad];
+            xyzzu_add_q(a, sh[quad + st], role);
+            if (role == 0) sh[quad] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) set_sums[blockIdx.x] = xyzzu_to_ext(sh[0]);
+}
+
 // Fixed-base table, one step: out[i] = 2^c * prev[i] (XYZZ; normalised to affine by ec_normalize afterwards)
 __global__ void __launch_bounds__(256) msm_table_step_kernel(const Affine* __restrict__ prev, XYZZ* __restrict__ out, uint32_t n, uint32_t c) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -577,6 +682,8 @@ __global__ void __launch_bounds__(256) msm_table_step_kernel(const Affine* __res
 static uint32_t g_window_override = 0;
 static size_t g_heavy_div = 32768;
 static size_t g_bin_entries = 8192;
+static bool g_quad_tail = true;
+void msm_set_quad_tail(bool on) { g_quad_tail = on; }
 static uint32_t g_accum_bs = 256;
 static bool g_global_order = true;  // false: bucket order local to a sort bin (measured 1.3-1.8x slower accumulation)
 void msm_set_bucket_order(int local) { g_global_order = local == 0; }
@@ -689,7 +796,7 @@ struct MsmLayout {
     uint32_t levels, s, rb, s2, s3;
     size_t max_chunks, max_heavy;
     size_t o_zero, o_zero_end, o_ccnt, o_ccur, o_hist, o_hcnt, o_cstart, o_tmp, o_vals, o_start, o_counts, o_perm, o_buckets, o_RA, o_CA, o_RR,
-        o_RC, o_CR, o_CC, o_sums, o_hb, o_hc, o_hs, o_ptrs, total;
+        o_RC, o_CR, o_CC, o_sums, o_partials, o_hb, o_hc, o_hs, o_ptrs, total;
 };
 
 static int msm_layout(size_t n, MsmLayout* L, uint32_t fuse, const MsmTable* tab) {
@@ -765,6 +872,7 @@ static int msm_layout(size_t n, MsmLayout* L, uint32_t fuse, const MsmTable* tab
     L->o_CR = carve(((size_t)ns << (L->s - L->s3)) * sizeof(XYZZu));
     L->o_CC = carve(((size_t)ns << L->s3) * sizeof(XYZZu));
     L->o_sums = carve((size_t)ns * sizeof(XYZZ));
+    L->o_partials = carve((size_t)ns * 16 * sizeof(XYZZu));
     L->o_hb = carve(L->max_heavy * sizeof(HeavyBucket));
     L->o_hc = carve(L->max_chunks * sizeof(HeavyChunk));
     L->o_hs = carve(L->max_chunks * sizeof(XYZZu));
@@ -863,15 +971,16 @@ static int msm_stage_b(Ctx* c, const MsmLayout& L, char* base, const Affine* d_p
 // Lanes per sum: every lane gets the same number of terms t, with t the smallest power of two that keeps the pass
 // within one wave per SIMD (a lone wave already saturates its SIMD's issue rate, so a second one only queues).
 static void rowcol_jobs(RowColArgs* ra, const XYZZu* in, XYZZu* out_rows, XYZZu* out_cols, uint32_t n_arr, uint32_t log_rows, uint32_t log_cols,
-                        uint32_t* n_blocks) {
+                        uint32_t* n_blocks, bool quad = false) {
     const uint64_t elems = (uint64_t)n_arr << (log_rows + log_cols);
     uint32_t t_log = 1;
-    while ((2 * elems) >> t_log > 65536) t_log++;
+    while (!quad && (2 * elems) >> t_log > 65536) t_log++;
     for (uint32_t kind = 0; kind < 2; kind++) {
         RowColJob* j = &ra->job[ra->n_jobs++];
         const uint32_t log_terms = kind ? log_rows : log_cols, log_sums = kind ? log_cols : log_rows;
         uint32_t g_log = log_terms > t_log ? log_terms - t_log : 0;
-        if (g_log > 8) g_log = 8;
+        const uint32_t g_max = quad ? 4 : 8;  // quads (of 16) or lanes (of 256) per sum
+        if (g_log > g_max) g_log = g_max;
         j->in = in;
         j->out = kind ? out_cols : out_rows;
         j->n_arr = n_arr;
@@ -881,7 +990,7 @@ static void rowcol_jobs(RowColArgs* ra, const XYZZu* in, XYZZu* out_rows, XYZZu*
         j->g_log = g_log;
         j->first_block = *n_blocks;
         const uint64_t tasks = (uint64_t)n_arr << log_sums;
-        const uint32_t per_block = 256u >> g_log;
+        const uint32_t per_block = (quad ? 16u : 256u) >> g_log;
         *n_blocks += (uint32_t)((tasks + per_block - 1) / per_block);
     }
 }
@@ -893,6 +1002,9 @@ static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_sums, hip
     XYZZu *CR = (XYZZu*)(base + L.o_CR), *CC = (XYZZu*)(base + L.o_CC);
     XYZZ* sums = (XYZZ*)(base + L.o_sums);
     const uint32_t ns = L.n_sets, cb = L.p.cb;
+    // few sets: the second row/column pass and the final scaling are latency chains on a handful of waves -- one quad of
+    // lanes per group operation (ecq.cuh).  Many sets (fused batches of the plain form) fill the chip: one lane each.
+    const bool quad = g_quad_tail && ns <= 64;
     int t4 = c->timer_begin("msm_reduce", s);
     FinalArgs fa;
     memset(&fa, 0, sizeof(fa));
@@ -921,9 +1033,12 @@ static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_sums, hip
         } else {
             memset(&ra, 0, sizeof(ra));
             nblk = 0;
-            rowcol_jobs(&ra, RA, RR, RC, ns, L.rb - L.s2, L.s2, &nblk);
-            rowcol_jobs(&ra, CA, CR, CC, ns, L.s - L.s3, L.s3, &nblk);
-            hipLaunchKernelGGL(msm_rowcol_kernel, dim3(nblk), dim3(256), 0, s, ra);
+            rowcol_jobs(&ra, RA, RR, RC, ns, L.rb - L.s2, L.s2, &nblk, quad);
+            rowcol_jobs(&ra, CA, CR, CC, ns, L.s - L.s3, L.s3, &nblk, quad);
+            if (quad)
+                hipLaunchKernelGGL(msm_rowcol_quad_kernel, dim3(nblk), dim3(64), 0, s, ra);
+            else
+                hipLaunchKernelGGL(msm_rowcol_kernel, dim3(nblk), dim3(256), 0, s, ra);
             H2_CHECK(hipGetLastError());
             set_arr(0, RR, L.rb - L.s2, 0, L.s + L.s2);
             set_arr(1, RC, L.s2, 0, L.s);
@@ -932,7 +1047,17 @@ static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_sums, hip
             fa.n_arr = 4;
         }
     }
-    hipLaunchKernelGGL(msm_final_kernel, dim3(ns), dim3(256), 0, s, fa, sums);
+    if (quad) {
+        uint32_t n_el = 0;
+        for (uint32_t i = 0; i < fa.n_arr; i++) n_el += fa.arr[i].len;
+        const uint32_t n_groups = (n_el + 15) / 16;  // <= 16: at most 4 arrays of 64
+        XYZZu* partials = (XYZZu*)(base + L.o_partials);
+        hipLaunchKernelGGL(msm_final_quad_kernel, dim3(ns * n_groups), dim3(64), 0, s, fa, n_groups, partials);
+        H2_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(msm_final_sum_kernel, dim3(ns), dim3(64), 0, s, (const XYZZu*)partials, n_groups, sums);
+    } else {
+        hipLaunchKernelGGL(msm_final_kernel, dim3(ns), dim3(256), 0, s, fa, sums);
+    }
     H2_CHECK(hipGetLastError());
     c->timer_end(t4, s);
     H2_CHECK(hipMemcpyAsync(h_sums, sums, (size_t)ns * sizeof(XYZZ), hipMemcpyDeviceToHost, s));
