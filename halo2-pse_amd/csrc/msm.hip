@@ -387,33 +387,39 @@ __device__ __forceinline__ void accum_signed(XYZZu& acc, const Affine* __restric
     xyzzu_add_affine<F>(acc, p, (v >> 31) != 0);
 }
 
-// B: one lane per bucket.  `bases` is the caller's point array (plain form) or the window table (fixed-base form).
+// B: 2^split_log lanes per bucket (one when split_log = 0): lane (bucket, sub) adds the bucket's entries sub, sub + S,
+// sub + 2S, ... into parts[bucket * S + sub].  A run with few buckets (a lone MSM of <= 2^17 pairs over a window table
+// has 2^16) would otherwise be one wave per SIMD walking ~30 dependent additions per lane.
+// `bases` is the caller's point array (plain form) or the window table (fixed-base form).
 __global__ void __launch_bounds__(256) msm_accum_kernel(const Affine* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                         const uint32_t* __restrict__ start, const uint32_t* __restrict__ counts,
-                                                        const uint32_t* __restrict__ perm, uint32_t n_buckets, uint32_t heavy_t,
-                                                        uint32_t chunk, XYZZu* __restrict__ buckets, uint32_t* __restrict__ heavy_counts,
+                                                        const uint32_t* __restrict__ perm, uint32_t n_buckets, uint32_t split_log, uint32_t heavy_t,
+                                                        uint32_t chunk, XYZZu* __restrict__ parts, uint32_t* __restrict__ heavy_counts,
                                                         HeavyBucket* __restrict__ heavy_buckets, HeavyChunk* __restrict__ heavy_chunks) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_buckets) return;
-    const uint32_t b = perm[t];  // buckets in descending size order
+    if ((t >> split_log) >= n_buckets) return;
+    const uint32_t S = 1u << split_log, sub = t & (S - 1);
+    const uint32_t b = perm[t >> split_log];  // buckets in descending size order
     uint32_t s = start[b], e = s + counts[b];
     XYZZu acc = xyzzu_identity();
     if (e - s > heavy_t) {
-        uint32_t nch = (e - s + chunk - 1) / chunk;
-        uint32_t slot = atomicAdd(&heavy_counts[1], nch);
-        uint32_t hb = atomicAdd(&heavy_counts[0], 1u);
-        HeavyBucket h = {b, slot, nch, 0};
-        heavy_buckets[hb] = h;
-        for (uint32_t q = 0; q < nch; q++) {
-            HeavyChunk ch = {s + q * chunk, (s + (q + 1) * chunk < e) ? s + (q + 1) * chunk : e};
-            heavy_chunks[slot + q] = ch;
+        if (sub == 0) {
+            uint32_t nch = (e - s + chunk - 1) / chunk;
+            uint32_t slot = atomicAdd(&heavy_counts[1], nch);
+            uint32_t hb = atomicAdd(&heavy_counts[0], 1u);
+            HeavyBucket h = {b, slot, nch, 0};
+            heavy_buckets[hb] = h;
+            for (uint32_t q = 0; q < nch; q++) {
+                HeavyChunk ch = {s + q * chunk, (s + (q + 1) * chunk < e) ? s + (q + 1) * chunk : e};
+                heavy_chunks[slot + q] = ch;
+            }
         }
-    } else if (s < e) {
+    } else if (s + sub < e) {
         // The point of the next entry is fetched before the current addition starts: with a window table the points
         // are gathers from hundreds of MB of HBM, and one addition (~2.3 k instructions) hides the whole miss.
-        uint32_t v = vals[s];
+        uint32_t v = vals[s + sub];
         Affine p = bases[v & 0x7fffffffu];
-        for (uint32_t i = s + 1; i < e; i++) {
+        for (uint32_t i = s + sub + S; i < e; i += S) {
             const uint32_t vn = vals[i];
             const Affine pn = bases[vn & 0x7fffffffu];
             xyzzu_add_affine<FqUA>(acc, p, (v >> 31) != 0);  // throughput-bound: explicit-mad multiplier
@@ -422,6 +428,17 @@ __global__ void __launch_bounds__(256) msm_accum_kernel(const Affine* __restrict
         }
         xyzzu_add_affine<FqUA>(acc, p, (v >> 31) != 0);
     }
+    parts[((size_t)b << split_log) + sub] = acc;
+}
+
+// B': bucket = sum of its 2^split_log parts (over-full buckets get the identity here and their sum from msm_heavy_final)
+__global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZu* __restrict__ parts, uint32_t n_buckets, uint32_t split_log,
+                                                          XYZZu* __restrict__ buckets) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_buckets) return;
+    const XYZZu* P = parts + ((size_t)b << split_log);
+    XYZZu acc = P[0];
+    for (uint32_t j = 1; j < (1u << split_log); j++) xyzzu_add(acc, P[j]);
     buckets[b] = acc;
 }
 
@@ -682,6 +699,8 @@ __global__ void __launch_bounds__(256) msm_table_step_kernel(const Affine* __res
 static uint32_t g_window_override = 0;
 static size_t g_heavy_div = 32768;
 static size_t g_bin_entries = 8192;
+static bool g_split_buckets = true;
+void msm_set_split_buckets(bool on) { g_split_buckets = on; }
 static bool g_quad_tail = true;
 void msm_set_quad_tail(bool on) { g_quad_tail = on; }
 static uint32_t g_accum_bs = 256;
@@ -754,7 +773,7 @@ static MsmPlan make_plan(size_t n, bool fused, const MsmTable* tab) {
     size_t t = (n * p.W) / g_heavy_div;
     if (t < 32) t = 32;
     const size_t mean = (p.shared ? n * p.W : n) >> p.cb;  // few buckets (narrow windows): the ordinary bucket is not "over-full"
-    if (t < 4 * mean) t = 4 * mean;
+    if (t < 8 * mean) t = 8 * mean;  // the buckets the narrow windows use hold twice the mean
     p.heavy_t = (uint32_t)t;
     p.chunk = 4096;
     return p;
@@ -792,10 +811,11 @@ struct MsmLayout {
     size_t n, E;        // pairs per MSM; upper bound of the entries of the run
     uint32_t K;         // buckets in total
     uint32_t L, C1, bin_shift;
+    uint32_t split_log;  // lanes per bucket of the accumulation = 2^split_log
     // reduction: levels 0..2 of row/column passes before the final kernel
     uint32_t levels, s, rb, s2, s3;
     size_t max_chunks, max_heavy;
-    size_t o_zero, o_zero_end, o_ccnt, o_ccur, o_hist, o_hcnt, o_cstart, o_tmp, o_vals, o_start, o_counts, o_perm, o_buckets, o_RA, o_CA, o_RR,
+    size_t o_zero, o_zero_end, o_ccnt, o_ccur, o_hist, o_hcnt, o_cstart, o_tmp, o_vals, o_start, o_counts, o_perm, o_buckets, o_parts, o_RA, o_CA, o_RR,
         o_RC, o_CR, o_CC, o_sums, o_partials, o_hb, o_hc, o_hs, o_ptrs, total;
 };
 
@@ -839,6 +859,11 @@ static int msm_layout(size_t n, MsmLayout* L, uint32_t fuse, const MsmTable* tab
     L->bin_shift = 0;
     const size_t mean_bucket = (p.shared ? n * p.W : n) >> p.cb;
     while ((mean_bucket >> L->bin_shift) > 100) L->bin_shift++;
+    // lanes per bucket: up to 8, while the run has fewer than 2^18 buckets (4 waves per SIMD) and the mean bucket holds at
+    // least two entries per lane
+    L->split_log = 0;
+    while (L->split_log < 3 && ((uint64_t)L->K << (L->split_log + 1)) <= (1u << 18) && (mean_bucket >> (L->split_log + 1)) >= 2) L->split_log++;
+    if (!g_split_buckets) L->split_log = 0;
     L->max_chunks = L->E / p.chunk + L->E / p.heavy_t + 16;  // sum of ceil(cnt/chunk) over buckets with cnt > heavy_t
     L->max_heavy = L->E / p.heavy_t + 16;
     // reduction geometry
@@ -865,6 +890,7 @@ static int msm_layout(size_t n, MsmLayout* L, uint32_t fuse, const MsmTable* tab
     L->o_counts = carve((size_t)K * 4);
     L->o_perm = carve((size_t)K * 4);
     L->o_buckets = carve((size_t)K * sizeof(XYZZu));
+    L->o_parts = L->split_log ? carve(((size_t)K << L->split_log) * sizeof(XYZZu)) : L->o_buckets;
     L->o_RA = carve(((size_t)ns << L->rb) * sizeof(XYZZu));
     L->o_CA = carve(((size_t)ns << L->s) * sizeof(XYZZu));
     L->o_RR = carve(((size_t)ns << (L->rb - L->s2)) * sizeof(XYZZu));
@@ -948,13 +974,19 @@ static int msm_stage_b(Ctx* c, const MsmLayout& L, char* base, const Affine* d_p
     XYZZu* hs = (XYZZu*)(base + L.o_hs);
     int t2 = c->timer_begin("msm_accum", s);
     hipEvent_t ke0 = nullptr, ke1 = nullptr;
+    XYZZu* parts = (XYZZu*)(base + L.o_parts);
+    const uint32_t lanes = L.K << L.split_log;
     if (c->timer_kernel("msm_accum", &ke0, &ke1) >= 0)  // the dispatch's own begin / end timestamps: no marker packets around it
-        hipExtLaunchKernelGGL(msm_accum_kernel, dim3((L.K + g_accum_bs - 1) / g_accum_bs), dim3(g_accum_bs), 0, s, ke0, ke1, 0, d_points, vals, start,
-                              counts, perm, L.K, p.heavy_t, p.chunk, buckets, hcnt, hb, hc);
+        hipExtLaunchKernelGGL(msm_accum_kernel, dim3((lanes + g_accum_bs - 1) / g_accum_bs), dim3(g_accum_bs), 0, s, ke0, ke1, 0, d_points, vals, start,
+                              counts, perm, L.K, L.split_log, p.heavy_t, p.chunk, parts, hcnt, hb, hc);
     else
-        hipLaunchKernelGGL(msm_accum_kernel, dim3((L.K + g_accum_bs - 1) / g_accum_bs), dim3(g_accum_bs), 0, s, d_points, vals, start, counts, perm,
-                           L.K, p.heavy_t, p.chunk, buckets, hcnt, hb, hc);
+        hipLaunchKernelGGL(msm_accum_kernel, dim3((lanes + g_accum_bs - 1) / g_accum_bs), dim3(g_accum_bs), 0, s, d_points, vals, start, counts, perm,
+                           L.K, L.split_log, p.heavy_t, p.chunk, parts, hcnt, hb, hc);
     H2_CHECK(hipGetLastError());
+    if (L.split_log) {
+        hipLaunchKernelGGL(msm_combine_kernel, dim3((L.K + 255) / 256), dim3(256), 0, s, (const XYZZu*)parts, L.K, L.split_log, buckets);
+        H2_CHECK(hipGetLastError());
+    }
     c->timer_end(t2, s);
     int t3 = c->timer_begin("msm_heavy", s);
     uint32_t hgrid = (uint32_t)(L.max_chunks < (size_t)c->sm_count * 4 ? L.max_chunks : (size_t)c->sm_count * 4);

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--bin-entries", type=int, default=0)
     ap.add_argument("--local-order", type=int, default=0)
     ap.add_argument("--quad-tail", type=int, default=1)
+    ap.add_argument("--split", type=int, default=1)
     ap.add_argument("--skew", action="store_true", help="prover-like scalars: 90 %% zero, 5 %% in {1, 2}, 5 %% uniform")
     args = ap.parse_args()
     h2 = load_pkg()
@@ -56,6 +57,7 @@ def main():
     h2.lib().h2hip_debug_set_msm_bin_entries(ctypes.c_size_t(args.bin_entries))
     h2.lib().h2hip_debug_set_msm_bucket_order(ctypes.c_int(args.local_order))
     h2.lib().h2hip_debug_set_msm_quad_tail(ctypes.c_int(args.quad_tail))
+    h2.lib().h2hip_debug_set_msm_split_buckets(ctypes.c_int(args.split))
     for lg in args.log_n:
         n = 1 << lg
         ds = h2.gen_scalars_device(0x5EED0001, n)
