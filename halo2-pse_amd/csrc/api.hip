@@ -24,6 +24,7 @@ void msm_set_bin_entries(size_t d);
 void msm_set_bucket_order(int local);
 void msm_set_quad_tail(bool on);
 void msm_set_split_buckets(bool on);
+void msm_set_rowcol(uint64_t lanes, bool use_asm);
 void ntt_set_smax(uint32_t v);
 void msm_set_reserved_cus(uint32_t k);
 uint32_t msm_get_reserved_cus();
@@ -1542,6 +1543,12 @@ int h2hip_debug_set_msm_max_chunk(size_t m) {
 // tuning hook: buckets above (entries of the MSM) / d go to the chunked path (default 32768; 0 restores it)
 int h2hip_debug_set_msm_heavy_div(size_t d) {
     msm_set_heavy_div(d);
+    return 0;
+}
+
+// tuning hook: lane budget of the first row/column pass (default 65536 = one wave per SIMD) and its multiplier flavour
+int h2hip_debug_set_msm_rowcol(uint64_t lanes, int use_asm) {
+    msm_set_rowcol(lanes, use_asm != 0);
     return 0;
 }
 

@@ -56,6 +56,7 @@ H2_HD XYZZu xyzzu_double_affine(const Fu& px, const Fu& py) {
 }
 
 // dbl-2008-s-1
+template <class QU = FqU>
 H2_HD XYZZu xyzzu_double(const XYZZu& p) {
     if (xyzzu_is_identity(p)) return p;
     XYZZu o;
@@ -113,6 +114,7 @@ H2_HD void xyzzu_add_mixed(XYZZu& acc, const Fu& px, const Fu& py) {
 }
 
 // a += b: add-2008-s with exceptional cases
+template <class QU = FqU>
 H2_HD void xyzzu_add(XYZZu& a, const XYZZu& b) {
     if (xyzzu_is_identity(b)) return;
     if (xyzzu_is_identity(a)) {
@@ -128,7 +130,7 @@ H2_HD void xyzzu_add(XYZZu& a, const XYZZu& b) {
     if (fu_maybe_zero_mod_p<QU>(p_)) {
         if (fu_is_zero_mod_p<QU>(p_)) {
             if (fu_is_zero_mod_p<QU>(r)) {
-                a = xyzzu_double(a);
+                a = xyzzu_double<QU>(a);
             } else {
                 a = xyzzu_identity();
             }

@@ -342,35 +342,36 @@ __global__ void __launch_bounds__(1024) msm_l2_kernel(const uint2* __restrict__ 
 }
 
 // A5: order the buckets by size (descending, 256 classes) with a counting sort.  hist[0..256) = class counts (from
-// msm_l2_kernel), hist[256..512) = per-class cursors, zeroed beforehand.
-__global__ void __launch_bounds__(256) msm_bucket_scatter_kernel(const uint32_t* __restrict__ counts, uint32_t n_buckets, uint32_t bin_shift,
-                                                                 uint32_t* __restrict__ hist, uint32_t* __restrict__ perm) {
-    __shared__ uint32_t scan[256], lh[256], lbase[256];
-    // exclusive scan of the 256 class counts (every block repeats it: 256 values)
-    uint32_t v = hist[threadIdx.x];
-    scan[threadIdx.x] = v;
-    lh[threadIdx.x] = 0;
+// msm_l2_kernel), hist[256..512) = per-class cursors, zeroed beforehand.  1024 lanes x 4 buckets per workgroup: one
+// returning atomic per (workgroup, class) on 256 addresses -- with 256-bucket workgroups those atomics, serialised per
+// address, were the whole 31 us of this kernel at 2^19 buckets.
+#define MSM_BS_PER 4u
+__global__ void __launch_bounds__(1024) msm_bucket_scatter_kernel(const uint32_t* __restrict__ counts, uint32_t n_buckets, uint32_t bin_shift,
+                                                                  uint32_t* __restrict__ hist, uint32_t* __restrict__ perm) {
+    __shared__ uint32_t scan[256], lh[256], lbase[256], ps[16];
+    const uint32_t t = threadIdx.x;
+    if (t < 256) lh[t] = 0;
+    uint32_t total;
+    const uint32_t excl = block_scan_base<1024>(hist, 256, 1, ps, &total);  // exclusive scan of the class counts (every block repeats it)
+    if (t < 256) scan[t] = excl;
     __syncthreads();
-    for (uint32_t off = 1; off < 256; off <<= 1) {
-        uint32_t add = threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
-        __syncthreads();
-        scan[threadIdx.x] += add;
-        __syncthreads();
+    uint32_t cls[MSM_BS_PER], rank[MSM_BS_PER];
+    const uint32_t b0 = (blockIdx.x * 1024 + t) * MSM_BS_PER;
+#pragma unroll
+    for (uint32_t j = 0; j < MSM_BS_PER; j++) {
+        cls[j] = 0;
+        rank[j] = 0;
+        if (b0 + j < n_buckets) {
+            cls[j] = size_class(counts[b0 + j], bin_shift);
+            rank[j] = atomicAdd(&lh[cls[j]], 1u);
+        }
     }
-    const uint32_t excl = scan[threadIdx.x] - v;
     __syncthreads();
-    scan[threadIdx.x] = excl;
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t cls = 0, rank = 0;
-    const bool live = t < n_buckets;
-    if (live) {
-        cls = size_class(counts[t], bin_shift);
-        rank = atomicAdd(&lh[cls], 1u);
-    }
+    if (t < 256 && lh[t]) lbase[t] = atomicAdd(&hist[256 + t], lh[t]);
     __syncthreads();
-    if (lh[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&hist[256 + threadIdx.x], lh[threadIdx.x]);
-    __syncthreads();
-    if (live) perm[scan[cls] + lbase[cls] + rank] = t;
+#pragma unroll
+    for (uint32_t j = 0; j < MSM_BS_PER; j++)
+        if (b0 + j < n_buckets) perm[scan[cls[j]] + lbase[cls[j]] + rank[j]] = b0 + j;
 }
 
 struct HeavyBucket {
@@ -507,6 +508,7 @@ struct RowColArgs {
     uint32_t n_jobs;
 };
 
+template <class F>
 __global__ void __launch_bounds__(256) msm_rowcol_kernel(RowColArgs args) {
     __shared__ XYZZu sh[256];
     uint32_t ji = 0;
@@ -531,10 +533,10 @@ __global__ void __launch_bounds__(256) msm_rowcol_kernel(RowColArgs args) {
             for (uint32_t i = g + G; i < terms; i += G) {
                 first += step;
                 const XYZZu nxt = first[0];
-                xyzzu_add(acc, cur);
+                xyzzu_add<F>(acc, cur);
                 cur = nxt;
             }
-            xyzzu_add(acc, cur);
+            xyzzu_add<F>(acc, cur);
         }
     }
     sh[threadIdx.x] = acc;
@@ -542,7 +544,7 @@ __global__ void __launch_bounds__(256) msm_rowcol_kernel(RowColArgs args) {
     for (uint32_t stride = G >> 1; stride >= 1; stride >>= 1) {
         if (g < stride) {
             XYZZu x = sh[threadIdx.x];
-            xyzzu_add(x, sh[threadIdx.x + stride]);
+            xyzzu_add<F>(x, sh[threadIdx.x + stride]);
             sh[threadIdx.x] = x;
         }
         __syncthreads();
@@ -699,6 +701,9 @@ __global__ void __launch_bounds__(256) msm_table_step_kernel(const Affine* __res
 static uint32_t g_window_override = 0;
 static size_t g_heavy_div = 32768;
 static size_t g_bin_entries = 8192;
+static uint64_t g_rowcol_lanes = 65536;
+static bool g_rowcol_asm = false;
+void msm_set_rowcol(uint64_t lanes, bool use_asm) { g_rowcol_lanes = lanes ? lanes : 65536; g_rowcol_asm = use_asm; }
 static bool g_split_buckets = true;
 void msm_set_split_buckets(bool on) { g_split_buckets = on; }
 static bool g_quad_tail = true;
@@ -955,7 +960,8 @@ static int msm_stage_a(Ctx* c, const MsmLayout& L, char* base, const Fe* const* 
                        g_global_order ? hist : (uint32_t*)nullptr);
     H2_CHECK(hipGetLastError());
     if (g_global_order) {
-        hipLaunchKernelGGL(msm_bucket_scatter_kernel, dim3((L.K + 255) / 256), dim3(256), 0, s, counts, L.K, L.bin_shift, hist, perm);
+        hipLaunchKernelGGL(msm_bucket_scatter_kernel, dim3((L.K + 1024 * MSM_BS_PER - 1) / (1024 * MSM_BS_PER)), dim3(1024), 0, s, counts, L.K, L.bin_shift,
+                           hist, perm);
         H2_CHECK(hipGetLastError());
     }
     c->timer_end(t1, s);
@@ -1006,7 +1012,7 @@ static void rowcol_jobs(RowColArgs* ra, const XYZZu* in, XYZZu* out_rows, XYZZu*
                         uint32_t* n_blocks, bool quad = false) {
     const uint64_t elems = (uint64_t)n_arr << (log_rows + log_cols);
     uint32_t t_log = 1;
-    while (!quad && (2 * elems) >> t_log > 65536) t_log++;
+    while (!quad && (2 * elems) >> t_log > g_rowcol_lanes) t_log++;
     for (uint32_t kind = 0; kind < 2; kind++) {
         RowColJob* j = &ra->job[ra->n_jobs++];
         const uint32_t log_terms = kind ? log_rows : log_cols, log_sums = kind ? log_cols : log_rows;
@@ -1056,7 +1062,10 @@ static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_sums, hip
         memset(&ra, 0, sizeof(ra));
         uint32_t nblk = 0;
         rowcol_jobs(&ra, buckets, RA, CA, ns, L.rb, L.s, &nblk);
-        hipLaunchKernelGGL(msm_rowcol_kernel, dim3(nblk), dim3(256), 0, s, ra);
+        if (g_rowcol_asm)
+            hipLaunchKernelGGL(msm_rowcol_kernel<FqUA>, dim3(nblk), dim3(256), 0, s, ra);
+        else
+            hipLaunchKernelGGL(msm_rowcol_kernel<FqU>, dim3(nblk), dim3(256), 0, s, ra);
         H2_CHECK(hipGetLastError());
         if (L.levels == 1) {
             set_arr(0, RA, L.rb, 0, L.s);
@@ -1070,7 +1079,7 @@ static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_sums, hip
             if (quad)
                 hipLaunchKernelGGL(msm_rowcol_quad_kernel, dim3(nblk), dim3(64), 0, s, ra);
             else
-                hipLaunchKernelGGL(msm_rowcol_kernel, dim3(nblk), dim3(256), 0, s, ra);
+                hipLaunchKernelGGL(msm_rowcol_kernel<FqU>, dim3(nblk), dim3(256), 0, s, ra);
             H2_CHECK(hipGetLastError());
             set_arr(0, RR, L.rb - L.s2, 0, L.s + L.s2);
             set_arr(1, RC, L.s2, 0, L.s);

@@ -307,6 +307,8 @@ int h2hip_debug_set_msm_max_chunk(size_t m);
 int h2hip_debug_rccl_gather_selftest(const uint64_t* partials_xyz, size_t count, uint64_t* out_xyz);
 /* buckets with more than (entries of the MSM) / d entries take the chunked path (default d = 32768; 0 restores it) */
 int h2hip_debug_set_msm_heavy_div(size_t d);
+/* first row/column pass of the reduction: lane budget (0 = 65536, one wave per SIMD) and explicit-mad multiplier (1) or plain (0) */
+int h2hip_debug_set_msm_rowcol(uint64_t lanes, int use_asm);
 /* accumulation of runs with fewer than 2^18 buckets: up to 8 lanes per bucket (1, default) or one (0) */
 int h2hip_debug_set_msm_split_buckets(int on);
 /* reduction tail: one quad of lanes per group operation (1, default) or one lane each (0) */

@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--local-order", type=int, default=0)
     ap.add_argument("--quad-tail", type=int, default=1)
     ap.add_argument("--split", type=int, default=1)
+    ap.add_argument("--rowcol-lanes", type=int, default=0)
+    ap.add_argument("--rowcol-asm", type=int, default=0)
     ap.add_argument("--skew", action="store_true", help="prover-like scalars: 90 %% zero, 5 %% in {1, 2}, 5 %% uniform")
     args = ap.parse_args()
     h2 = load_pkg()
@@ -58,6 +60,7 @@ def main():
     h2.lib().h2hip_debug_set_msm_bucket_order(ctypes.c_int(args.local_order))
     h2.lib().h2hip_debug_set_msm_quad_tail(ctypes.c_int(args.quad_tail))
     h2.lib().h2hip_debug_set_msm_split_buckets(ctypes.c_int(args.split))
+    h2.lib().h2hip_debug_set_msm_rowcol(ctypes.c_uint64(args.rowcol_lanes), ctypes.c_int(args.rowcol_asm))
     for lg in args.log_n:
         n = 1 << lg
         ds = h2.gen_scalars_device(0x5EED0001, n)
