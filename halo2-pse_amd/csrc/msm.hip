@@ -734,11 +734,14 @@ static uint32_t plain_window(size_t n, bool fused) {
     // that the top window is not a handful of over-full buckets
     // a fused batch has count times the buckets for the same chain lengths: narrower windows pay
     if (fused && lg >= 13 && lg <= 18) return lg <= 13 ? 10 : lg <= 16 ? 12 : lg == 17 ? 13 : 14;
+    // swept on MI355X after the round-2 sort / reduction (tools/msm_bench.py --no-fixed --windows ...).  255 = 15 x 17: with
+    // c = 15 or 17 every window is full width (no narrow windows crowding half of the buckets), which is worth more than
+    // the window count alone says: 2^20 1.96 ms at c = 16, 1.73 ms at c = 17; 2^24 24.4 -> 21.6 ms
     if (lg <= 8) return 7;
     if (lg <= 12) return 10;
-    if (lg <= 15) return 13;
-    if (lg <= 18) return 15;
-    return 16;
+    if (lg <= 14) return 13;
+    if (lg <= 17) return 15;
+    return 17;
 }
 
 // window width a fixed-base table is built with for n pinned points: all windows share one bucket set, so the
@@ -755,8 +758,8 @@ uint32_t msm_table_window(size_t n) {
     const uint32_t lg = floor_log2(n);
     // swept on MI355X (tools/msm_bench.py --windows): up to 2^17 points c = 17 (a lone MSM would take c = 20 -- 0.70 instead
     // of 0.78 ms at 2^17 -- but the prover's fused batches pay the 2 * 2^(c-1) additions of the reduction once per MSM:
-    // 0.19 ms per MSM of a 16 x 2^17 batch at c = 17); 2^18..2^22: c = 20; beyond: c = 22
-    uint32_t c = lg <= 12 ? 13 : lg <= 17 ? 17 : lg <= 22 ? 20 : 22;  // up to 2^12 points the MSM is all reduction tail: few buckets
+    // 0.18 ms per MSM of a 16 x 2^17 batch at c = 17); 2^18..2^21: c = 20; from 2^22: c = 22 (4.87 against 5.00 ms there)
+    uint32_t c = lg <= 12 ? 13 : lg <= 17 ? 17 : lg <= 21 ? 20 : 22;  // up to 2^12 points the MSM is all reduction tail: few buckets
     return normalise_window(c);
 }
 
