@@ -417,16 +417,43 @@ __global__ void __launch_bounds__(256) msm_accum_kernel(const Affine* __restrict
         }
     } else if (s + sub < e) {
         // The point of the next entry is fetched before the current addition starts: with a window table the points
-        // are gathers from hundreds of MB of HBM, and one addition (~2.3 k instructions) hides the whole miss.
+        // are gathers from hundreds of MB of HBM, and one addition (~2.3 k instructions) hides the whole miss.  The fetch
+        // is an LDS-DMA (global_load_lds_dwordx4, per-lane source address, lane-linear destination): holding the next
+        // point in registers instead costs 16 of them and with that the fourth wave per SIMD.
+        __shared__ uint4 pbuf[4][4][64];  // [wave][16-byte chunk of the point][lane]
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        auto issue = [&](uint32_t v) {
+            const char* g = reinterpret_cast<const char*>(&bases[v & 0x7fffffffu]);
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 16 * ch),
+                                                 (__attribute__((address_space(3))) void*)&pbuf[wave][ch][0], 16, 0, 0);
+        };
+        auto take = [&]() {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            Affine p;
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) {
+                const uint4 q = pbuf[wave][ch][lane];
+                Fe& f = ch < 2 ? p.x : p.y;
+                f.l[4 * (ch & 1)] = q.x;
+                f.l[4 * (ch & 1) + 1] = q.y;
+                f.l[4 * (ch & 1) + 2] = q.z;
+                f.l[4 * (ch & 1) + 3] = q.w;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the buffer is free for the next fetch
+            return p;
+        };
         uint32_t v = vals[s + sub];
-        Affine p = bases[v & 0x7fffffffu];
+        issue(v);
         for (uint32_t i = s + sub + S; i < e; i += S) {
             const uint32_t vn = vals[i];
-            const Affine pn = bases[vn & 0x7fffffffu];
+            const Affine p = take();
+            issue(vn);
             xyzzu_add_affine<FqUA>(acc, p, (v >> 31) != 0);  // throughput-bound: explicit-mad multiplier
             v = vn;
-            p = pn;
         }
+        const Affine p = take();
         xyzzu_add_affine<FqUA>(acc, p, (v >> 31) != 0);
     }
     parts[((size_t)b << split_log) + sub] = acc;
