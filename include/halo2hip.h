@@ -315,7 +315,7 @@ int h2hip_debug_set_msm_split_buckets(int on);
 int h2hip_debug_set_msm_quad_tail(int on);
 /* 1: accumulate order = buckets by size inside each sort bin only; 0 (default): global size order */
 int h2hip_debug_set_msm_bucket_order(int local);
-/* target entries per coarse bin of the MSM's two-level sort (default 16384 = one LDS tile; 0 restores it) */
+/* target entries per coarse bin of the MSM's two-level sort (default 8192; 0 restores it) */
 int h2hip_debug_set_msm_bin_entries(size_t d);
 /* CUs reserved for the sort / reduce streams of a batched MSM (0 = none: every split measured slower) */
 int h2hip_debug_set_reserved_cus(uint32_t k);
