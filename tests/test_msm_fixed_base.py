@@ -351,3 +351,30 @@ def test_rccl_gather_path_on_this_box(h2, oracle, golden):
     assert rc == 0, h2.lib().h2hip_last_error().decode()
     for j in range(3):
         assert np.array_equal(aff(h2, out[j]), oracle.g1_to_affine(parts[j])), j
+
+
+def test_allgather_fold_over_rccl_single_rank():
+    """bench.py's N > 1 exchange (halo2-pse_amd/dist.py) with the real backend: a one-rank `nccl` (= RCCL) process group on
+    this box's GPU takes the 96-byte partial up through pinned memory, all-gathers it and folds it back to the same point"""
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", HSA_ENABLE_IPC_MODE_LEGACY="0")
+import torch, torch.distributed as dist
+from conftest import load_pkg
+from importlib import import_module
+h2 = load_pkg(); h2dist = import_module("halo2_pse_amd.dist")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+h2.init(0)
+ds = h2.gen_scalars_device(1, 1000); dp = h2.gen_points_device(2, 1000)
+part = h2.msm_device(ds, dp)
+for _ in range(3):
+    tot = h2dist.allgather_fold(part, h2, device=torch.device("cuda", 0))
+print("RESULT", bool(np.array_equal(h2.g1_to_affine(tot), h2.g1_to_affine(part))))
+dist.destroy_process_group()
+""" % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "RESULT True" in r.stdout
