@@ -1319,7 +1319,7 @@ int msm_device(Ctx* c, const Fe* d_scalars, const Affine* d_bases, size_t n, XYZ
 // normalisation back to affine), in slices of 2^22 points so the XYZZ scratch stays at 512 MB.
 int msm_table_build(Ctx* c, const Affine* d_points, size_t n, uint32_t cw, Affine* d_table, hipStream_t s) {
     const uint32_t W = (255 + cw - 1) / cw, q = 255 - W * (cw - 1);
-    H2_CHECK(hipMemcpyAsync(d_table, d_points, n * sizeof(Affine), hipMemcpyDeviceToDevice, s));
+    if (d_table != d_points) H2_CHECK(hipMemcpyAsync(d_table, d_points, n * sizeof(Affine), hipMemcpyDeviceToDevice, s));  // row 0 = the points
     const size_t slice = (size_t)1 << 22;
     const size_t m_max = n < slice ? n : slice;
     int rc = c->ecfft_ws.ensure(m_max * sizeof(XYZZ));
