@@ -142,7 +142,7 @@ def inlib_child(args):
     W = info[2]
     res = {"n_devices": n_dev, "device_ids": ids, "pairs_total": n, "window_bits": info[1], "windows": W, "pin_s": pin_s,
            "table_bytes_total": info[3], "ms_per_msm": t * 1e3, "value": n * W / t, "unit": "G1-adds/s", "pairs_per_s": n / t,
-           "gather": os.environ.get("HALO2_HIP_GATHER", "rccl"),
+           "gather": "host (duplicate device ids: rehearsal)" if len(set(ids)) < len(ids) else os.environ.get("HALO2_HIP_GATHER", "rccl"),
            "note": "host-pointer h2hip_msm_bn254 (scalars cross PCIe inside the call: %d MiB per device), bases pinned per device" % ((32 << args.log_n) >> 20),
            "result_affine_x0": int(h2.g1_to_affine(out)[0])}
     h2.bases_unpin(bs)
