@@ -24,6 +24,7 @@ void msm_set_bin_entries(size_t d);
 void msm_set_bucket_order(int local);
 void msm_set_quad_tail(bool on);
 void msm_set_split_buckets(bool on);
+void msm_set_fuse_limits(size_t entries, size_t max_n);
 void msm_set_rowcol(uint64_t lanes, bool use_asm);
 void ntt_set_smax(uint32_t v);
 void msm_set_reserved_cus(uint32_t k);
@@ -1543,6 +1544,12 @@ int h2hip_debug_set_msm_max_chunk(size_t m) {
 // tuning hook: buckets above (entries of the MSM) / d go to the chunked path (default 32768; 0 restores it)
 int h2hip_debug_set_msm_heavy_div(size_t d) {
     msm_set_heavy_div(d);
+    return 0;
+}
+
+// tuning hook: a fused run holds at most `entries` entries (default 2^26) and fusing applies up to `max_n` pairs per MSM (default 2^18); 0 = default
+int h2hip_debug_set_msm_fuse_limits(size_t entries, size_t max_n) {
+    msm_set_fuse_limits(entries, max_n);
     return 0;
 }
 

@@ -1254,6 +1254,9 @@ static int msm_fused_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_h
     return c->ws_release(s);
 }
 
+// measured (tools/fuse_big.py, 8 MSMs per batch, per MSM): 2^19 pairs fused 0.66 ms / pipelined 0.69 ms, 2^20 pairs fused 1.24 / pipelined 1.16
+static size_t g_fuse_entries = (size_t)1 << 26, g_fuse_max_n = (size_t)1 << 19;
+void msm_set_fuse_limits(size_t entries, size_t max_n) { g_fuse_entries = entries ? entries : ((size_t)1 << 26); g_fuse_max_n = max_n ? max_n : ((size_t)1 << 19); }
 static bool g_fuse_small = true;
 void msm_set_fuse_small(bool on) { g_fuse_small = on; }
 
@@ -1283,16 +1286,16 @@ int msm_batch_device(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, c
             tsub = &sub;
             points = sub.table;
         }
-        // up to 2^18 pairs each: fused runs of at most 2^26 entries, MSM_MAX_C1 << MSM_MAX_L buckets and MSM_MAX_C1
+        // up to 2^19 pairs each: fused runs of at most 2^26 entries, MSM_MAX_C1 << MSM_MAX_L buckets and MSM_MAX_C1
         // bucket sets; larger MSMs: pipelined over streams
         const MsmPlan fp = make_plan(m, true, tsub);
         const size_t per_msm = m * fp.W;
         const size_t sets = fp.shared ? 1 : fp.W;
-        size_t fuse_max = per_msm ? ((size_t)1 << 26) / per_msm : 0;
+        size_t fuse_max = per_msm ? g_fuse_entries / per_msm : 0;
         const size_t by_buckets = (((size_t)MSM_MAX_C1 << MSM_MAX_L) >> fp.cb) / sets, by_sets = MSM_MAX_C1 / sets;
         if (fuse_max > by_buckets) fuse_max = by_buckets;
         if (fuse_max > by_sets) fuse_max = by_sets;
-        if (g_fuse_small && count > 1 && m <= ((size_t)1 << 18) && fuse_max >= 2) {
+        if (g_fuse_small && count > 1 && m <= g_fuse_max_n && fuse_max >= 2) {
             for (size_t j0 = 0; j0 < count; j0 += fuse_max) {
                 const size_t g = count - j0 < fuse_max ? count - j0 : fuse_max;
                 int rc = g == 1 ? msm_batch_chunk(c, ptrs.data() + j0, scalars_on_host, points, tsub, m, 1, part.data() + j0, s)

@@ -102,7 +102,7 @@ int h2hip_msm_bn254_device(const void* d_scalars, const void* d_bases_xy, size_t
 /* `count` independent MSMs of n pairs each over the SAME bases: out_xyz[12*j..] = sum_i scalars[j][i] * bases[i].
  * This is what create_proof does when it commits its columns back to back (plonk/prover.rs:361-365:
  * `params.commit_lagrange(poly, blind)` for every advice polynomial; lookup/prover.rs:127-132, :291;
- * vanishing/prover.rs:104).  Results equal `count` separate h2hip_msm_bn254 calls.  Up to 2^18 pairs the MSMs of a batch
+ * vanishing/prover.rs:104).  Results equal `count` separate h2hip_msm_bn254 calls.  Up to 2^19 pairs the MSMs of a batch
  * run fused (one sort / accumulate / reduce over the windows of all of them); larger ones are pipelined whole over three
  * streams (sort of j+1 and reduction of j-1 under the accumulation of j). */
 int h2hip_msm_bn254_batch(const uint64_t* const* scalars, const uint64_t* bases_xy, size_t n, size_t count, uint64_t* out_xyz);
@@ -307,6 +307,8 @@ int h2hip_debug_set_msm_max_chunk(size_t m);
 int h2hip_debug_rccl_gather_selftest(const uint64_t* partials_xyz, size_t count, uint64_t* out_xyz);
 /* buckets with more than (entries of the MSM) / d entries take the chunked path (default d = 32768; 0 restores it) */
 int h2hip_debug_set_msm_heavy_div(size_t d);
+/* fused batches: at most `entries` entries per fused run (0 = 2^26), MSMs of at most `max_n` pairs are fused (0 = 2^19) */
+int h2hip_debug_set_msm_fuse_limits(size_t entries, size_t max_n);
 /* first row/column pass of the reduction: lane budget (0 = 65536, one wave per SIMD) and explicit-mad multiplier (1) or plain (0) */
 int h2hip_debug_set_msm_rowcol(uint64_t lanes, int use_asm);
 /* accumulation of runs with fewer than 2^18 buckets: up to 8 lanes per bucket (1, default) or one (0) */
@@ -319,7 +321,7 @@ int h2hip_debug_set_msm_bucket_order(int local);
 int h2hip_debug_set_msm_bin_entries(size_t d);
 /* CUs reserved for the sort / reduce streams of a batched MSM (0 = none: every split measured slower) */
 int h2hip_debug_set_reserved_cus(uint32_t k);
-/* batches of MSMs of up to 2^18 pairs: fused into one run (1, default) or pipelined over streams (0) */
+/* batches of MSMs of up to 2^19 pairs: fused into one run (1, default) or pipelined over streams (0) */
 int h2hip_debug_set_msm_fuse_small(int on);
 /* largest log2 tile of an NTT pass (4..10; default 8, 9 beyond 2^24 points) */
 int h2hip_debug_set_ntt_smax(uint32_t v);
