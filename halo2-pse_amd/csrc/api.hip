@@ -24,6 +24,7 @@ void msm_set_bin_entries(size_t d);
 void msm_set_bucket_order(int local);
 void msm_set_quad_tail(bool on);
 void msm_set_split_buckets(bool on);
+void ecfft_set_quad(bool on);
 void msm_set_fuse_limits(size_t entries, size_t max_n);
 void msm_set_rowcol(uint64_t lanes, bool use_asm);
 void ntt_set_smax(uint32_t v);
@@ -1544,6 +1545,12 @@ int h2hip_debug_set_msm_max_chunk(size_t m) {
 // tuning hook: buckets above (entries of the MSM) / d go to the chunked path (default 32768; 0 restores it)
 int h2hip_debug_set_msm_heavy_div(size_t d) {
     msm_set_heavy_div(d);
+    return 0;
+}
+
+// tuning hook: g_to_lagrange layers with one quad of lanes per butterfly up to k = 14 (1, default) or one lane (0)
+int h2hip_debug_set_g2l_quad(int on) {
+    ecfft_set_quad(on != 0);
     return 0;
 }
 

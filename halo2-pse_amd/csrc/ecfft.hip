@@ -15,6 +15,7 @@
 // affine output is canonical, so it is compared limb for limb.
 #include <string.h>
 
+#include "ecq.cuh"
 #include "engine.h"
 #include "glv.cuh"
 
@@ -111,6 +112,75 @@ __global__ void __launch_bounds__(256) ecfft_layer_kernel(EcfftLayer L) {
     L.out[ib] = lo;
 }
 
+// The same ladder with one QUAD of lanes per butterfly (ecq.cuh): up to k = 14 a layer is at most 2^13 butterflies -- a
+// fraction of the chip's 65 536 SIMD lanes -- and the 130 doublings + 65 additions of a ladder are a pure latency chain.  The four
+// lanes of a quad hold the same point and digits; the 15-entry table is built by every lane for itself (mixed additions).
+__device__ XYZZu ec_mul_affine_glv_q(const Affine& p, const GlvScalar& k, uint32_t role) {
+    if (affine_is_identity(p)) return xyzzu_identity();
+    const uint32_t BETA_I[9] = {0x0a337995u, 0x158d1d23u, 0x189c9b98u, 0x12fa4e45u, 0x185faadcu, 0x0176f16du, 0x0eed93bau, 0x14291140u, 0x000c0afeu};
+    const Fu x1 = fu_from_ext(p.x);
+    Fu y1 = fu_from_ext(p.y), y2 = y1;
+    const Fu x2 = fu_mul<QU>(x1, fu_const<QU>(BETA_I));
+    if (k.neg1) y1 = fu_neg(y1);
+    if (k.neg2) y2 = fu_neg(y2);
+    XYZZu tab[16];
+    tab[0] = xyzzu_identity();
+    tab[1] = xyzzu_identity();
+    xyzzu_add_mixed<QU>(tab[1], x1, y1);
+    tab[2] = xyzzu_double_affine<QU>(x1, y1);
+    tab[3] = tab[2];
+    xyzzu_add_mixed<QU>(tab[3], x1, y1);
+    tab[4] = xyzzu_identity();
+    xyzzu_add_mixed<QU>(tab[4], x2, y2);
+    tab[8] = xyzzu_double_affine<QU>(x2, y2);
+    tab[12] = tab[8];
+    xyzzu_add_mixed<QU>(tab[12], x2, y2);
+    for (int b = 1; b < 4; b++)
+        for (int a = 1; a < 4; a++) {
+            tab[a + 4 * b] = tab[a + 4 * (b - 1)];
+            xyzzu_add_mixed<QU>(tab[a + 4 * b], x2, y2);
+        }
+    XYZZu acc = xyzzu_identity();
+    for (int i = 64; i >= 0; i--) {
+        acc = xyzzu_double_q(xyzzu_double_q(acc, role), role);
+        const uint32_t d1 = (k.k1[i >> 4] >> ((i & 15) * 2)) & 3, d2 = (k.k2[i >> 4] >> ((i & 15) * 2)) & 3;
+        const uint32_t d = d1 | (d2 << 2);
+        if (d) xyzzu_add_q(acc, tab[d], role);
+    }
+    return acc;
+}
+
+__global__ void __launch_bounds__(256) ecfft_layer_quad_kernel(EcfftLayer L) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t tid = gid >> 2;
+    const uint32_t role = (uint32_t)gid & 3;
+    const uint64_t n = 1ull << L.log_n;
+    if (tid >= n / 2) return;
+    const uint64_t half = 1ull << L.s;
+    const uint64_t i = tid & (half - 1), blk = tid >> L.s;
+    const uint64_t ia = (blk << (L.s + 1)) + i, ib = ia + half;
+    uint64_t la = ia, lb = ib;
+    if (L.s == 0) {
+        la = __brevll(ia) >> (64 - L.log_n);
+        lb = __brevll(ib) >> (64 - L.log_n);
+    }
+    const Affine a = L.in[la], b = L.in[lb];
+    XYZZ t;
+    if (i == 0) {
+        t = xyzz_from_affine(b);
+    } else {
+        const GlvScalar w = L.tw[i << (L.log_n - 1 - L.s)];
+        t = xyzzu_to_ext(ec_mul_affine_glv_q(b, w, role));
+    }
+    if (role != 0) return;  // the two closing additions are canonical arithmetic: one lane
+    XYZZ hi = t, lo = t;
+    lo.y = fe_neg<FqP>(t.y);
+    xyzz_add_mixed(hi, a);
+    xyzz_add_mixed(lo, a);
+    L.out[ia] = hi;
+    L.out[ib] = lo;
+}
+
 __global__ void __launch_bounds__(256) ec_scale_kernel(const Affine* in, XYZZ* out, uint64_t n, Scalar256 e) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= n) return;
@@ -133,7 +203,9 @@ __global__ void __launch_bounds__(256) ec_normalize_kernel(const XYZZ* in, Affin
             if (!fe_is_zero(zzz)) acc = fe_mul<FqP>(acc, zzz);
         }
     }
-    Fe inv = fe_inv<FqP>(acc);
+    // the one inversion per lane on the unsaturated multiplier (E-form in: fu_from_ext gives the I-form limbs for free;
+    // canonical E-form out through the exact reduction): 2.6x fewer instructions than fe_inv's saturated Fermat chain
+    Fe inv = fu_mul_canon<FqU>(fu_inv<FqU>(fu_from_ext(acc)), fu_one_e<FqU>());
 #pragma unroll
     for (int j = EC_NORM_CHUNK - 1; j >= 0; j--) {
         const uint64_t idx = tid + (uint64_t)j * lanes;
@@ -160,6 +232,9 @@ __global__ void __launch_bounds__(256) ecfft_twiddle_kernel(GlvScalar* tw, uint6
     const Fe c = fe_to_canonical<FrP>(fe_pow_u64<FrP>(omega_inv, tid));
     tw[tid] = glv_decompose(c.l);
 }
+
+static bool g_ecfft_quad = true;
+void ecfft_set_quad(bool on) { g_ecfft_quad = on; }
 
 static int normalize_launch(const XYZZ* in, Affine* out, uint64_t n, hipStream_t s) {
     const uint64_t lanes = (n + EC_NORM_CHUNK - 1) / EC_NORM_CHUNK;
@@ -200,7 +275,10 @@ int g_to_lagrange_device(Ctx* c, const Affine* d_g, uint32_t k, Affine* d_out, h
     const Affine* src = d_g;
     for (uint32_t layer = 0; layer < k; layer++) {
         EcfftLayer L = {src, d_xyzz, d_tw, k, layer};
-        hipLaunchKernelGGL(ecfft_layer_kernel, dim3((uint32_t)((n / 2 + 255) / 256)), dim3(256), 0, s, L);
+        if (g_ecfft_quad && k <= 14)  // few butterflies per layer (<= 2^13: fewer lanes than SIMD slots even four to a butterfly)
+            hipLaunchKernelGGL(ecfft_layer_quad_kernel, dim3((uint32_t)((2 * n + 255) / 256)), dim3(256), 0, s, L);
+        else
+            hipLaunchKernelGGL(ecfft_layer_kernel, dim3((uint32_t)((n / 2 + 255) / 256)), dim3(256), 0, s, L);
         H2_CHECK(hipGetLastError());
         if ((rc = normalize_launch(d_xyzz, d_out, n, s))) return rc;
         src = d_out;

@@ -394,4 +394,26 @@ H2_HD Fe fu_mul_canon(const Fu& x, const Fu& c) {
     return o;
 }
 
+// a^-1 (mod p) by Fermat on the unsaturated multiplier: I-form in (|value| < 32 p, limbs < 2^29: fu_from_ext output or
+// any normalised value), I-form out in (-0.2 p, 1.2 p); 0 -> 0.  253 squarings + one multiply per set bit of p - 2:
+// ~78 k instructions against ~204 k for fe_inv's saturated CIOS -- the chain that sets the latency of a batched
+// normalisation with few lanes.
+template <class U>
+H2_HD Fu fu_inv(const Fu& a) {
+    typedef typename U::Sat P;
+    uint32_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = P::MOD[i];
+    e[0] -= 2;  // MOD odd, low limb >= 2
+    Fu r = fu_mul<U>(a, fu_one_i<U>());  // bring |value| inside (-0.2 p, 1.2 p), same residue
+    const Fu base = r;
+    int top = 255;
+    while (top > 0 && !((e[top >> 5] >> (top & 31)) & 1)) top--;
+    for (int i = top - 1; i >= 0; i--) {
+        r = fu_sqr<U>(r);
+        if ((e[i >> 5] >> (i & 31)) & 1) r = fu_mul<U>(r, base);
+    }
+    return r;
+}
+
 }  // namespace h2

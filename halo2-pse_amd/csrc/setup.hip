@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) kzg_setup_scalars_kernel(Fe s, Fe mult, F
     if (i >= n) return;
     e_g[i] = fe_to_canonical<FrP>(fe_pow_u64<FrP>(s, i));                            // :76-81
     const Fe root_pow = fe_pow_u64<FrP>(root, i);                                    // :99
-    const Fe d = fe_inv<FrP>(fe_sub<FrP>(s, root_pow));                              // (s - root_pow).invert(), :100
+    const Fe d = fu_mul_canon<FrU>(fu_inv<FrU>(fu_from_ext(fe_sub<FrP>(s, root_pow))), fu_one_e<FrU>());  // (s - root_pow).invert(), :100
     e_gl[i] = fe_to_canonical<FrP>(fe_mul<FrP>(fe_mul<FrP>(mult, root_pow), d));     // :100
 }
 

@@ -96,6 +96,13 @@ static void test_field(const char* name) {
         CHECK(fu_is_zero_mod_p<U>(z));
         if (!fe_is_zero(a)) CHECK(!fu_is_zero_mod_p<U>(fu_norm(sa)) || false);
     }
+    // fu_inv (Fermat on the unsaturated multiplier) against fe_inv, E-form in and out as ec_normalize uses it
+    for (int it = 0; it < 300; it++) {
+        Fe a = rand_fe<P>(it < 8 ? it % 4 : 0);
+        Fe got = fu_mul_canon<U>(fu_inv<U>(fu_from_ext(a)), one_e);
+        CHECK(fe_eq(got, fe_inv<P>(a)));
+        if (!fe_is_zero(a)) CHECK(fe_eq(fe_mul<P>(got, a), fe_one<P>()));
+    }
     // k*p and k*p + 1 for |k| <= 8
     Fu pf = fu_const<U>(U::P);
     for (int k = -8; k <= 8; k++) {
