@@ -28,6 +28,7 @@ void ecfft_set_quad(bool on);
 void msm_set_fuse_limits(size_t entries, size_t max_n);
 void msm_set_rowcol(uint64_t lanes, bool use_asm);
 void ntt_set_smax(uint32_t v);
+void ntt_set_two_pass(uint32_t lo, uint32_t hi);
 void msm_set_reserved_cus(uint32_t k);
 uint32_t msm_get_reserved_cus();
 uint32_t msm_get_window(size_t n);
@@ -1609,6 +1610,12 @@ int h2hip_debug_set_msm_fuse_small(int on) {
 
 int h2hip_debug_set_ntt_smax(uint32_t v) {
     ntt_set_smax(v);
+    return 0;
+}
+
+// tuning hook: sizes 2^lo..2^hi (within 18..22) take the two-pass plan; hi < lo turns it off
+int h2hip_debug_set_ntt_two_pass(uint32_t lo, uint32_t hi) {
+    ntt_set_two_pass(lo, hi);
     return 0;
 }
 

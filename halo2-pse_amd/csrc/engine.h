@@ -56,6 +56,9 @@ struct TwiddleTable {
     Fu* lo = nullptr;  // omega^i, i < 2^lo_bits                                  (I-form limbs, fieldu.cuh)
     Fu* hi = nullptr;  // omega^(i << lo_bits), i < 2^(log_n - lo_bits) (at least 1 entry)
     uint32_t lo_bits = 0;
+    // two-pass plan (ntt.hip): the tile DFT's own twiddles w_R^i, i < R / 2, for R = 2^stage_s[t]
+    Fu* stage[2] = {nullptr, nullptr};
+    uint32_t stage_s[2] = {0, 0};
 };
 
 // Fixed-base window table of a pinned base array (msm.hip): row j (of `stride` points) = 2^(c j) * P, j < W

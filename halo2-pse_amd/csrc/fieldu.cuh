@@ -20,6 +20,8 @@
 //   (a*b/2^261, a*b/2^261 + p).  fu_add / fu_sub are limb-wise on int32: callers keep |l| < 2^31.
 //   fu_norm propagates carries: limbs 0..7 back in [0, 2^29), value unchanged.
 #pragma once
+#include <utility>
+
 #include "field.cuh"
 
 namespace h2 {
@@ -226,6 +228,77 @@ H2_HD void fu_column_done(int64_t& acc) {
 template <class U, bool SQR, bool TWO, bool HI>
 H2_HD Fu fu_fused(const Fu& a, const Fu& b, const Fu& c, const Fu& d, const Fu& h);
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "fieldu_chain.inc"
+
+// The explicit-mad flavour of fu_fused (U::ASM): column K of the product scan, its multiply-adds issued as one asm statement
+// per operand kind (a*b, -c*d, m*p) so that no hazard padding lands between them.
+template <class U, bool SQR, bool TWO, bool HI, int K>
+struct FuAsmColumn {
+    static constexpr int LO = K > 8 ? K - 8 : 0, TOP = K < 8 ? K : 8;
+    static constexpr int NP = SQR ? (TOP - LO) / 2 + 1 : TOP - LO + 1;  // products of this column (the square's symmetric half)
+    static constexpr int NR = K < 9 ? K : 17 - K;                       // reduction terms m[i] * P[K - i] already known
+
+    template <int... I>
+    __device__ __forceinline__ static void products(int64_t& acc, const Fu& a, const Fu& b, const int32_t (&a2)[9], std::integer_sequence<int, I...>) {
+        if constexpr (SQR) {
+            const int32_t x[NP] = {((LO + I) < (K - LO - I) ? a2[LO + I] : a.l[LO + I])...};
+            const int32_t y[NP] = {a.l[K - LO - I]...};
+            fu_chain_ss<NP>(acc, x, y);
+        } else {
+            const int32_t x[NP] = {a.l[LO + I]...};
+            const int32_t y[NP] = {b.l[K - LO - I]...};
+            fu_chain_ss<NP>(acc, x, y);
+        }
+    }
+    template <int... I>
+    __device__ __forceinline__ static void second(int64_t& acc, const int32_t (&nc)[9], const Fu& d, std::integer_sequence<int, I...>) {
+        const int32_t x[TOP - LO + 1] = {nc[LO + I]...};
+        const int32_t y[TOP - LO + 1] = {d.l[K - LO - I]...};
+        fu_chain_ss<TOP - LO + 1>(acc, x, y);
+    }
+    template <int... I>
+    __device__ __forceinline__ static void reduction(int64_t& acc, const uint32_t (&m)[9], std::integer_sequence<int, I...>) {
+        constexpr int FIRST = K < 9 ? 0 : K - 8;  // i runs FIRST .. FIRST + NR - 1
+        const uint32_t x[NR] = {m[FIRST + I]...};
+        const uint32_t y[NR] = {U::P[K - FIRST - I]...};
+        fu_chain_mp<NR>(acc, x, y);
+    }
+    __device__ __forceinline__ static void run(int64_t& acc, uint32_t (&m)[9], Fu& r, const Fu& a, const Fu& b, const int32_t (&a2)[9],
+                                                const int32_t (&nc)[9], const Fu& d, const Fu& h) {
+        products(acc, a, b, a2, std::make_integer_sequence<int, NP>());
+        if constexpr (TWO) second(acc, nc, d, std::make_integer_sequence<int, TOP - LO + 1>());
+        if constexpr (NR > 0) reduction(acc, m, std::make_integer_sequence<int, NR>());
+        if constexpr (K < 9) {
+            m[K] = ((uint32_t)acc * U::INV) & H2_MASK29;
+            acc += (int64_t)((uint64_t)m[K] * U::P[0]);  // one add between two asm statements: nothing to reassociate
+            acc >>= 29;                                  // exact
+        } else {
+            if constexpr (HI) acc -= (int64_t)h.l[K - 9];
+            r.l[K - 9] = (int32_t)((uint32_t)acc & H2_MASK29);
+            acc >>= 29;
+        }
+    }
+};
+
+template <class U, bool SQR, bool TWO, bool HI, int... K>
+__device__ __forceinline__ Fu fu_fused_asm(const Fu& a, const Fu& b, const Fu& c, const Fu& d, const Fu& h, std::integer_sequence<int, K...>) {
+    int64_t acc = 0;
+    uint32_t m[9];
+    int32_t a2[9], nc[9];
+    Fu r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        a2[i] = SQR ? a.l[i] * 2 : 0;
+        nc[i] = TWO ? -c.l[i] : 0;
+    }
+    (FuAsmColumn<U, SQR, TWO, HI, K>::run(acc, m, r, a, b, a2, nc, d, h), ...);
+    if (HI) acc -= (int64_t)h.l[8];
+    r.l[8] = (int32_t)acc;
+    return r;
+}
+#endif
+
 template <class U>
 H2_HD Fu fu_mul(const Fu& a, const Fu& b) {
     return fu_fused<U, false, false, false>(a, b, a, a, a);
@@ -253,6 +326,9 @@ H2_HD Fu fu_fused(const Fu& a, const Fu& b, const Fu& c, const Fu& d, const Fu& 
         __int128 bound = (__int128)9 * ma * mb + (TWO ? (__int128)9 * mc * md : 0) + ((__int128)9 << 58) + ((__int128)1 << 36);
         assert(bound < ((__int128)1 << 63));
     }
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (U::ASM) return fu_fused_asm<U, SQR, TWO, HI>(a, b, c, d, h, std::make_integer_sequence<int, 17>());
 #endif
     int64_t acc = 0;
     uint32_t m[9];

@@ -7,13 +7,24 @@
 //
 // Schedule (decimation in frequency, one HBM round trip per pass): pass t takes blocks of length
 // M, views each as R x (M/R) (R = 2^s rows at stride M/R), loads J adjacent columns into LDS,
-// runs the R-point DFT per column in LDS with the w_R table staged in LDS, multiplies output row
-// k of column lo by w_M^(k*lo) and stores it back to row k.  After the strided passes the
-// result is in digit-reversed order by blocks; the last pass (M = R, contiguous blocks) undoes
-// that on its store, writing J consecutive outputs per row so stores stay coalesced.  The
-// pointwise steps that surround best_fft in poly/domain.rs (zeta coset scaling + zero padding
-// on the way in, :246-247; 1/n and zeta^-1 scaling on the way out, :294, :355-360) are fused
-// into the first load and the last store.
+// runs the R-point DFT per column in LDS, multiplies output row k of column lo by w_M^(k*lo) and
+// stores it back to row k.  After the strided passes the result is in digit-reversed order by
+// blocks; the last pass (M = R, contiguous blocks) undoes that on its store, writing J consecutive
+// outputs per row so stores stay coalesced.  The pointwise steps that surround best_fft in
+// poly/domain.rs (zeta coset scaling + zero padding on the way in, :246-247; 1/n and zeta^-1
+// scaling on the way out, :294, :355-360) are fused into the first load and the last store.
+//
+// Two plans.  Three (or more) passes of 2^7..2^9-point tiles, 256 lanes and J = 4 or 2 columns at
+// once (ntt_strided_kernel / ntt_final_kernel), for every size but 2^20..2^22; those take two
+// passes of 2^10 / 2^11-point tiles (ntt2_*_kernel: R / 4 lanes, one column at a time, first and
+// last butterfly rounds in registers): 13 instead of 14.5 field multiplications per element and
+// one HBM round trip fewer.  Both are bound by VALU issue (the 9 x 29-bit multiplier is ~80 % of
+// the instructions), so what matters is the instruction count and keeping four waves per SIMD
+// busy: the tile twiddles w_R^i come from a per-domain table in global memory (every workgroup
+// reads the same few KB; keeping them out of LDS is what lets a fourth 256-point workgroup, or a
+// second 2^11-point one, share a CU), the LDS image is swizzled conflict-free (lds_swz), and rounds
+// whose groups stay inside one wave's 256 points synchronise the wave only.
+#include <stddef.h>
 #include <string.h>
 
 #include <vector>
@@ -28,6 +39,7 @@ struct NttPass {
     Fe* dst;
     const Fu* tw_lo;
     const Fu* tw_hi;
+    const Fu* stage_tw;  // this pass's tile twiddles w_R^i, i < R / 2 (every workgroup reads the same few KB: L1 / L2 hits)
     uint64_t in_len;
     uint32_t log_n, log_m, s, log_j, lo_bits;
     uint32_t first, in_scale, out_scale;
@@ -60,12 +72,49 @@ __device__ __forceinline__ Fu tw_pow(const NttPass& p, uint64_t e) {
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t k, uint32_t s) { return __brev(k) >> (32 - s); }
 
-// kernel-argument constants are picked with selects: a dynamic index would send the whole array to scratch
-__device__ __forceinline__ Fu pick3(const Fu c[3], uint32_t m) {
-    Fu r = c[0];
-    if (m == 1) r = c[1];
-    if (m == 2) r = c[2];
+// The scale constants are read from the kernel-argument segment itself (the pass descriptor is the first argument of every
+// kernel here): indexing the by-value copy with a lane-dependent residue would send the whole array to scratch.
+__device__ __forceinline__ Fu pick3(size_t field_offset, uint32_t m) {
+    typedef const __attribute__((address_space(4))) int32_t* KernArg;
+    KernArg k = (KernArg)__builtin_amdgcn_kernarg_segment_ptr() + field_offset / 4 + 9 * m;
+    Fu r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = k[i];
     return r;
+}
+#define NTT_IN3 offsetof(NttPass, in3)
+#define NTT_OUT3 offsetof(NttPass, out3)
+
+// LDS image index of point e.  A point is 9 dwords, so the bank of its dword c is (9 e + c) mod 32: the 32 lanes of a DS
+// access group are conflict-free exactly when their e differ mod 32.  Every access pattern of these kernels varies five
+// bit positions of e across such a group -- {2..6}, {0,1,4,5,6}, {0..3,6} in the rounds of half-size 1, 4, 16, five
+// consecutive positions in the bit-reversed loads, {0,1,2,s,s+1} in the row-major stores -- so the low five bits are
+// XORed with a GF(2)-linear image of the higher ones whose columns c5, c6, ... continue the sequence e0..e4 by
+// c[k+5] = c[k] ^ c[k+2] ^ c[k+4]: any five consecutive columns are independent, and so is each of the other sets.
+__device__ __forceinline__ uint32_t lds_swz(uint32_t e) {
+    const uint32_t t = e >> 5;
+    uint32_t m = (0u - (t & 1)) & 21u;
+    m ^= (0u - ((t >> 1) & 1)) & 31u;
+    m ^= (0u - ((t >> 2) & 1)) & 11u;
+    m ^= (0u - ((t >> 3) & 1)) & 22u;
+    m ^= (0u - ((t >> 4) & 1)) & 25u;
+    m ^= (0u - ((t >> 5) & 1)) & 7u;
+    m ^= (0u - ((t >> 6) & 1)) & 14u;
+    m ^= (0u - ((t >> 7) & 1)) & 28u;
+    return e ^ m;
+}
+
+// A lane's radix-4 group of half-size h <= 64 lies inside the 256 consecutive points its own wave works on (lane q of a
+// round takes point group q), so rounds up to there hand their results on within the wave: the LDS image only has to be
+// ordered for the wave (DS operations of one wave complete in issue order), not for the workgroup.
+__device__ __forceinline__ void round_sync(uint32_t next_log_h, bool next_is_radix4) {
+    if (next_is_radix4 && next_log_h <= 6) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
 }
 
 // R-point DFT on J columns held in LDS as x[col*R + bitrev(r)] on entry, x[col*R + k] on exit (decimation in
@@ -81,13 +130,15 @@ __device__ __forceinline__ void dft_lds(Fu* x, const Fu* wtab, uint32_t s, uint3
     const uint32_t nq = (R << log_j) >> 2;
     for (; log_h + 2 <= s; log_h += 2) {
         const uint32_t h = 1u << log_h;
+        const uint32_t d1 = lds_swz(h), d2 = lds_swz(2 * h), d3 = d1 ^ d2;
         for (uint32_t q = threadIdx.x; q < nq; q += NTT_THREADS) {
             uint32_t col = q >> (s - 2);
             uint32_t i = q & ((R >> 2) - 1);
             uint32_t off = i & (h - 1);
             uint32_t blk = i >> log_h;
-            uint32_t base = (col << s) + (blk << (log_h + 2)) + off;
-            Fu x0 = x[base], x1 = x[base + h], x2 = x[base + 2 * h], x3 = x[base + 3 * h];
+            const uint32_t base = lds_swz((col << s) + (blk << (log_h + 2)) + off);  // the bits of j * h are clear: swz(base + j h) = swz(base) ^ swz(j h)
+            const uint32_t e1 = base ^ d1, e2 = base ^ d2, e3 = base ^ d3;
+            Fu x0 = x[base], x1 = x[e1], x2 = x[e2], x3 = x[e3];
             if (log_h) {
                 Fu wa = wtab[off << (s - 1 - log_h)];
                 x1 = fu_mul<FrUA>(x1, wa);
@@ -97,11 +148,11 @@ __device__ __forceinline__ void dft_lds(Fu* x, const Fu* wtab, uint32_t s, uint3
             Fu u2 = fu_mul<FrUA>(y2, wtab[off << (s - 2 - log_h)]);
             Fu u3 = fu_mul<FrUA>(y3, wtab[(off + h) << (s - 2 - log_h)]);
             x[base] = fu_norm(fu_add(y0, u2));
-            x[base + 2 * h] = fu_norm(fu_sub(y0, u2));
-            x[base + h] = fu_norm(fu_add(y1, u3));
-            x[base + 3 * h] = fu_norm(fu_sub(y1, u3));
+            x[e2] = fu_norm(fu_sub(y0, u2));
+            x[e1] = fu_norm(fu_add(y1, u3));
+            x[e3] = fu_norm(fu_sub(y1, u3));
         }
-        __syncthreads();
+        round_sync(log_h + 2, log_h + 4 <= s);
     }
     if (log_h < s) {  // odd s: last stage on its own
         const uint32_t h = 1u << log_h;
@@ -111,8 +162,8 @@ __device__ __forceinline__ void dft_lds(Fu* x, const Fu* wtab, uint32_t s, uint3
             uint32_t i = bf & ((R >> 1) - 1);
             uint32_t off = i & (h - 1);
             uint32_t blk = i >> log_h;
-            uint32_t i0 = (col << s) + (blk << (log_h + 1)) + off;
-            uint32_t i1 = i0 + h;
+            uint32_t i0 = lds_swz((col << s) + (blk << (log_h + 1)) + off);
+            uint32_t i1 = i0 ^ lds_swz(h);
             Fu a = x[i0], t = x[i1];
             if (log_h) t = fu_mul<FrUA>(t, wtab[off << (s - 1 - log_h)]);
             x[i0] = fu_add(a, t);
@@ -128,7 +179,7 @@ __device__ __forceinline__ Fu ntt_load(const NttPass& p, const Fe* src, uint64_t
         Fu v = fu_slice(src[gi]);
         if (p.in_scale) {
             uint32_t m = (uint32_t)(gi % 3);
-            if (m) v = fu_mul<FrUA>(v, pick3(p.in3, m));
+            if (m) v = fu_mul<FrUA>(v, pick3(NTT_IN3, m));
         }
         return v;
     }
@@ -142,24 +193,22 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_strided_kernel(NttPass p) {
     Fe* dst = ntt_dst(p);
     Fu* x = reinterpret_cast<Fu*>(ntt_lds_raw);
     const uint32_t R = 1u << p.s, J = 1u << p.log_j;
-    Fu* wtab = x + (R << p.log_j);
     const uint32_t log_l = p.log_m - p.s;                 // L = M/R columns per block
     const uint32_t log_gpb = log_l - p.log_j;             // column groups per block
     const uint64_t u = blockIdx.x;
     const uint64_t base = (u >> log_gpb) << p.log_m;
     const uint64_t lo0 = (u & ((1ull << log_gpb) - 1)) << p.log_j;
-    for (uint32_t i = threadIdx.x; i < (R >> 1); i += NTT_THREADS) wtab[i] = tw_pow(p, (uint64_t)i << (p.log_n - p.s));
     for (uint32_t idx = threadIdx.x; idx < (R << p.log_j); idx += NTT_THREADS) {
         uint32_t r = idx >> p.log_j, jj = idx & (J - 1);
-        x[(jj << p.s) + bitrev(r, p.s)] = ntt_load(p, src, base + ((uint64_t)r << log_l) + lo0 + jj);
+        x[lds_swz((jj << p.s) + bitrev(r, p.s))] = ntt_load(p, src, base + ((uint64_t)r << log_l) + lo0 + jj);
     }
     __syncthreads();
-    dft_lds(x, wtab, p.s, p.log_j);
+    dft_lds(x, p.stage_tw, p.s, p.log_j);
     for (uint32_t idx = threadIdx.x; idx < (R << p.log_j); idx += NTT_THREADS) {
         uint32_t k = idx >> p.log_j, jj = idx & (J - 1);
         uint64_t lo = lo0 + jj;
         uint64_t e = ((uint64_t)k * lo) << (p.log_n - p.log_m);  // w_M^(k*lo) = omega^((N/M)*k*lo)
-        dst[base + ((uint64_t)k << log_l) + lo] = fu_mul_canon<FrUA>(x[(jj << p.s) + k], tw_pow(p, e));
+        dst[base + ((uint64_t)k << log_l) + lo] = fu_mul_canon<FrUA>(x[lds_swz((jj << p.s) + k)], tw_pow(p, e));
     }
 }
 
@@ -168,9 +217,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_final_kernel(NttPass p) {
     Fe* dst = ntt_dst(p);
     Fu* x = reinterpret_cast<Fu*>(ntt_lds_raw);
     const uint32_t R = 1u << p.s, J = 1u << p.log_j;
-    Fu* wtab = x + (R << p.log_j);
     const uint64_t g = blockIdx.x;
-    for (uint32_t i = threadIdx.x; i < (R >> 1); i += NTT_THREADS) wtab[i] = tw_pow(p, (uint64_t)i << (p.log_n - p.s));
     for (uint32_t idx = threadIdx.x; idx < (R << p.log_j); idx += NTT_THREADS) {
         uint32_t jj = idx >> p.s, r = idx & (R - 1);
         // block whose digit-reversed index is g*J + jj
@@ -179,25 +226,17 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_final_kernel(NttPass p) {
             bi = (bi << p.prev_s[t]) | (v & ((1ull << p.prev_s[t]) - 1));
             v >>= p.prev_s[t];
         }
-        x[(jj << p.s) + bitrev(r, p.s)] = ntt_load(p, src, (bi << p.s) + r);
+        x[lds_swz((jj << p.s) + bitrev(r, p.s))] = ntt_load(p, src, (bi << p.s) + r);
     }
     __syncthreads();
-    dft_lds(x, wtab, p.s, p.log_j);
+    dft_lds(x, p.stage_tw, p.s, p.log_j);
     const uint32_t log_nb = p.log_n - p.s;
     const Fu one_i = fu_one_i<FrUA>();
     for (uint32_t idx = threadIdx.x; idx < (R << p.log_j); idx += NTT_THREADS) {
         uint32_t k = idx >> p.log_j, jj = idx & (J - 1);
         uint64_t oi = ((uint64_t)k << log_nb) + (g << p.log_j) + jj;
-        Fu c = p.out_scale ? pick3(p.out3, (uint32_t)(oi % 3)) : one_i;
-        dst[oi] = fu_mul_canon<FrUA>(x[(jj << p.s) + k], c);
-    }
-}
-
-// n = 1: best_fft is the identity; only the fused scales apply
-__global__ void ntt_n1_kernel(NttPass p) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        Fu v = ntt_load(p, ntt_src(p), 0);
-        ntt_dst(p)[0] = fu_mul_canon<FrUA>(v, p.out_scale ? p.out3[0] : fu_one_i<FrUA>());
+        Fu c = p.out_scale ? pick3(NTT_OUT3, (uint32_t)(oi % 3)) : one_i;
+        dst[oi] = fu_mul_canon<FrUA>(x[lds_swz((jj << p.s) + k)], c);
     }
 }
 
@@ -206,6 +245,142 @@ __host__ __device__ __forceinline__ Fu fu_i_from_fe(const Fe& x) {
     Fe t = x;
     for (int k = 0; k < 5; k++) t = fe_dbl<FrP>(t);
     return fu_slice(t);
+}
+
+// ---- two-pass plan for 2^20 < n <= 2^22: tiles of R = 2^10 or 2^11 points -------------------------------------------
+// One HBM round trip fewer than three passes of 2^7..2^8, and 14 instead of 16 multiplications per element (no second
+// inter-pass twiddle).  A 2048-point tile with 64-byte rows would be 147 KB of limbs plus a 36 KB twiddle table -- more
+// than a CU's LDS -- so a workgroup of R / 4 lanes takes TWO columns (64-byte rows: whole HBM bursts both ways) but runs
+// their DFTs one after the other through ONE R-point LDS image; the column that waits sits in registers as loaded, the
+// finished one as canonical limbs.  The tile DFT's own twiddles w_R^i come from a table built once per (omega, R).
+// One column's R-point DFT, registers to registers: lane t (of R / 4) brings rows t + m R/4 (m = 0..3) and leaves with
+// outputs t + m R/4.  Bit-reversed, its four rows are the consecutive points 4 i' .. 4 i' + 3 (i' = bitrev(t)) in the order
+// m = 0, 2, 1, 3, so the first stage pair (or, for odd s, the lone first stage) runs on the loaded values; and the last
+// round's group of half-size R / 4 is exactly {t + m R/4}, so its results never go back to LDS.  In between, the rounds
+// exchange through the image x as dft_lds does.
+__device__ __forceinline__ void dft_col(Fu* x, const Fu* wtab, uint32_t s, const Fu (&v)[4], Fu (&res)[4]) {
+    const uint32_t t = threadIdx.x;
+    const uint32_t b0 = lds_swz(bitrev(t, s - 2) << 2);  // swz(4 i' + j) = swz(4 i') ^ j
+    uint32_t log_h;
+    if (s & 1) {
+        x[b0] = fu_norm(fu_add(v[0], v[2]));
+        x[b0 ^ 1] = fu_norm(fu_sub(v[0], v[2]));
+        x[b0 ^ 2] = fu_norm(fu_add(v[1], v[3]));
+        x[b0 ^ 3] = fu_norm(fu_sub(v[1], v[3]));
+        log_h = 1;
+    } else {
+        const Fu y0 = fu_add(v[0], v[2]), y1 = fu_sub(v[0], v[2]), y2 = fu_add(v[1], v[3]), y3 = fu_sub(v[1], v[3]);
+        const Fu u2 = fu_mul<FrUA>(y2, wtab[0]);
+        const Fu u3 = fu_mul<FrUA>(y3, wtab[1u << (s - 2)]);
+        x[b0] = fu_norm(fu_add(y0, u2));
+        x[b0 ^ 2] = fu_norm(fu_sub(y0, u2));
+        x[b0 ^ 1] = fu_norm(fu_add(y1, u3));
+        x[b0 ^ 3] = fu_norm(fu_sub(y1, u3));
+        log_h = 2;
+    }
+    __syncthreads();
+    for (;; log_h += 2) {
+        const bool last = log_h + 2 == s;
+        const uint32_t h = 1u << log_h;
+        const uint32_t d1 = lds_swz(h), d2 = lds_swz(2 * h), d3 = d1 ^ d2;
+        const uint32_t off = t & (h - 1), blk = t >> log_h;
+        const uint32_t base = lds_swz((blk << (log_h + 2)) + off);
+        const uint32_t e1 = base ^ d1, e2 = base ^ d2, e3 = base ^ d3;
+        Fu x0 = x[base], x1 = x[e1], x2 = x[e2], x3 = x[e3];
+        const Fu wa = wtab[off << (s - 1 - log_h)];
+        x1 = fu_mul<FrUA>(x1, wa);
+        x3 = fu_mul<FrUA>(x3, wa);
+        const Fu y0 = fu_add(x0, x1), y1 = fu_sub(x0, x1), y2 = fu_add(x2, x3), y3 = fu_sub(x2, x3);
+        const Fu u2 = fu_mul<FrUA>(y2, wtab[off << (s - 2 - log_h)]);
+        const Fu u3 = fu_mul<FrUA>(y3, wtab[(off + h) << (s - 2 - log_h)]);
+        if (last) {
+            res[0] = fu_norm(fu_add(y0, u2));
+            res[2] = fu_norm(fu_sub(y0, u2));
+            res[1] = fu_norm(fu_add(y1, u3));
+            res[3] = fu_norm(fu_sub(y1, u3));
+            break;
+        }
+        x[base] = fu_norm(fu_add(y0, u2));
+        x[e2] = fu_norm(fu_sub(y0, u2));
+        x[e1] = fu_norm(fu_add(y1, u3));
+        x[e3] = fu_norm(fu_sub(y1, u3));
+        round_sync(log_h + 2, true);
+    }
+    __syncthreads();  // the image is free for the next column
+}
+
+template <class F>
+__device__ __forceinline__ void four(F&& f) {
+    f(0u);
+    f(1u);
+    f(2u);
+    f(3u);
+}
+
+// pass 1 of 2: columns lo0 .. lo0 + J - 1 of the R x L view (L = N / R), rows at stride L.  A column's 32-byte pieces of a
+// row are read and written one column at a time; the J pieces of a row share cache lines, so all but the first read hit L2
+// and the writes meet there before they go out.
+__global__ void __launch_bounds__(512, 4) ntt2_strided_kernel(NttPass p) {
+    const Fe* src = ntt_src(p);
+    Fe* dst = ntt_dst(p);
+    Fu* x = reinterpret_cast<Fu*>(ntt_lds_raw);
+    const uint32_t T = blockDim.x;  // R / 4
+    const uint32_t log_l = p.log_n - p.s;
+    const uint64_t lo0 = (uint64_t)blockIdx.x << p.log_j;
+#pragma unroll 1
+    for (uint32_t c = 0; c < (1u << p.log_j); c++) {
+        const uint64_t lo = lo0 + c;
+        Fu v[4], y[4];
+        four([&](uint32_t m) __attribute__((always_inline)) {
+            const uint64_t r = threadIdx.x + m * T;
+            v[m] = ntt_load(p, src, (r << log_l) + lo);
+        });
+        dft_col(x, p.stage_tw, p.s, v, y);
+        four([&](uint32_t m) __attribute__((always_inline)) {
+            const uint64_t k = threadIdx.x + m * T;
+            dst[(k << log_l) + lo] = fu_mul_canon<FrUA>(y[m], tw_pow(p, k * lo));  // w_N^(k * lo)
+        });
+    }
+}
+
+// pass 2 of 2: contiguous blocks v0 .. v0 + J - 1 of R points; output k of block v goes to k * (N / R) + v
+__global__ void __launch_bounds__(512, 4) ntt2_final_kernel(NttPass p) {
+    const Fe* src = ntt_src(p);
+    Fe* dst = ntt_dst(p);
+    Fu* x = reinterpret_cast<Fu*>(ntt_lds_raw);
+    const uint32_t T = blockDim.x;  // R / 4
+    const uint32_t log_nb = p.log_n - p.s;
+    const uint64_t v0 = (uint64_t)blockIdx.x << p.log_j;
+    const Fu one_i = fu_one_i<FrUA>();
+#pragma unroll 1
+    for (uint32_t c = 0; c < (1u << p.log_j); c++) {
+        const uint64_t vb = v0 + c;
+        Fu v[4], y[4];
+        four([&](uint32_t m) __attribute__((always_inline)) {
+            const uint64_t r = threadIdx.x + m * T;
+            v[m] = fu_slice(src[(vb << p.s) + r]);
+        });
+        dft_col(x, p.stage_tw, p.s, v, y);
+        four([&](uint32_t m) __attribute__((always_inline)) {
+            const uint64_t k = threadIdx.x + m * T;
+            const uint64_t oi = (k << log_nb) + vb;
+            const Fu cst = p.out_scale ? pick3(NTT_OUT3, (uint32_t)(oi % 3)) : one_i;
+            dst[oi] = fu_mul_canon<FrUA>(y[m], cst);
+        });
+    }
+}
+
+__global__ void stage_twiddle_build_kernel(Fe omega, uint32_t shift, uint32_t count, Fu* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = fu_i_from_fe(fe_pow_u64<FrP>(omega, (uint64_t)i << shift));
+}
+
+// n = 1: best_fft is the identity; only the fused scales apply
+__global__ void ntt_n1_kernel(NttPass p) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        Fu v = ntt_load(p, ntt_src(p), 0);
+        ntt_dst(p)[0] = fu_mul_canon<FrUA>(v, p.out_scale ? p.out3[0] : fu_one_i<FrUA>());
+    }
 }
 
 __global__ void twiddle_build_kernel(Fe omega, Fu* lo, uint32_t n_lo, Fu* hi, uint32_t n_hi, uint32_t lo_bits) {
@@ -241,10 +416,50 @@ static int get_twiddles(Ctx* c, const Fe& omega, uint32_t log_n, hipStream_t s, 
         for (auto& kv : c->twiddles) {
             (void)hipFree(kv.second.lo);
             (void)hipFree(kv.second.hi);
+            if (kv.second.stage[1] != kv.second.stage[0]) (void)hipFree(kv.second.stage[1]);
+            (void)hipFree(kv.second.stage[0]);
         }
         c->twiddles.clear();
     }
     c->twiddles[key] = t;
+    *out = t;
+    return 0;
+}
+
+// the two-pass plan's tile twiddles w_R^i (i < R / 2) for R = 2^s1 and 2^s2, built once per domain
+static int get_stage_twiddles(Ctx* c, const Fe& omega, uint32_t log_n, uint32_t s1, uint32_t s2, hipStream_t s, TwiddleTable* out) {
+    TwiddleKey key;
+    for (int i = 0; i < 8; i++) key.omega[i] = omega.l[i];
+    key.log_n = log_n;
+    auto it = c->twiddles.find(key);
+    if (it == c->twiddles.end()) {
+        set_error("ntt: stage twiddles asked before the domain's table");
+        return 1;
+    }
+    TwiddleTable& t = it->second;
+    const uint32_t want[2] = {s1, s2};
+    if (t.stage[0] && (t.stage_s[0] != s1 || t.stage_s[1] != s2)) {  // the plan changed under a tuning hook
+        H2_CHECK(hipDeviceSynchronize());
+        if (t.stage[1] != t.stage[0]) (void)hipFree(t.stage[1]);
+        (void)hipFree(t.stage[0]);
+        t.stage[0] = t.stage[1] = nullptr;
+    }
+    for (int k = 0; k < 2; k++) {
+        if (t.stage[k]) continue;
+        if (k == 1 && want[1] == want[0]) {
+            t.stage[1] = t.stage[0];
+            t.stage_s[1] = want[1];
+            break;
+        }
+        const uint32_t cnt = 1u << (want[k] - 1);
+        Fu* d = nullptr;
+        H2_CHECK(hipMalloc((void**)&d, (size_t)cnt * sizeof(Fu)));
+        hipLaunchKernelGGL(stage_twiddle_build_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, omega, log_n - want[k], cnt, d);
+        H2_CHECK(hipGetLastError());
+        H2_CHECK(hipStreamSynchronize(s));  // built once per domain; later calls may use another stream
+        t.stage[k] = d;
+        t.stage_s[k] = want[k];
+    }
     *out = t;
     return 0;
 }
@@ -281,6 +496,14 @@ int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const uint64_t* h_t, uint
 
 static uint32_t g_ntt_smax = 8;
 void ntt_set_smax(uint32_t v) { g_ntt_smax = v < 4 ? 4 : (v > 10 ? 10 : v); }
+// Sizes 2^lo..2^hi take the two-pass plan (tiles of 2^10 or 2^11 points, ntt2_*_kernel): measured on MI355X
+// (tools/ntt_two_pass.py) 14 % faster than three passes at 2^20, 9 % at 2^21, 5 % at 2^22; below, too few workgroups.
+static uint32_t g_ntt_two_lo = 20, g_ntt_two_hi = 22;
+static bool g_ntt2_attr[64];
+void ntt_set_two_pass(uint32_t lo, uint32_t hi) {
+    g_ntt_two_lo = lo < 18 ? 18 : lo;
+    g_ntt_two_hi = hi > 22 ? 22 : hi;
+}
 
 // pass radices: one pass up to 2^10, otherwise ceil(log_n / smax) passes of near-equal radix
 static int plan_passes(uint32_t log_n, uint32_t s_out[4]) {
@@ -326,8 +549,14 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
     int rc0 = c->ws_acquire(s);
     if (rc0) return rc0;
     int tid = c->timer_begin("ntt", s);
+    const bool two = log_n >= g_ntt_two_lo && log_n <= g_ntt_two_hi;
     uint32_t S[4];
-    const int P = log_n ? plan_passes(log_n, S) : 1;
+    int P = log_n ? plan_passes(log_n, S) : 1;
+    if (two) {
+        P = 2;
+        S[0] = (log_n + 1) / 2;
+        S[1] = log_n - S[0];
+    }
     Fe* ws = nullptr;
     int rc;
     if (P > 1) {
@@ -375,12 +604,38 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
     TwiddleTable tw;
     rc = get_twiddles(c, omega, log_n, s, &tw);
     if (rc) return rc;
+    if ((rc = get_stage_twiddles(c, omega, log_n, S[0], S[P - 1], s, &tw))) return rc;  // the plans hand out at most two radices
     p.tw_lo = tw.lo;
     p.tw_hi = tw.hi;
     p.lo_bits = tw.lo_bits;
+    if (two) {
+        if (c->device >= 0 && c->device < 64 && !g_ntt2_attr[c->device]) {  // a 2^11-point image: more than the default 64 KB of dynamic LDS
+            H2_CHECK(hipFuncSetAttribute((const void*)ntt2_strided_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
+            H2_CHECK(hipFuncSetAttribute((const void*)ntt2_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
+            g_ntt2_attr[c->device] = true;
+        }
+        p.log_m = log_n;
+        p.log_j = 1;  // two columns (64-byte rows): four halve the workgroups and measure 6 % slower at 2^22, 24 % at 2^20
+        for (int t = 0; t < 2; t++) {
+            p.s = S[t];
+            p.first = (t == 0);
+            p.stage_tw = tw.stage[t];
+            bind(t == 0 ? FIRST : WS, t == 0 ? WS : DATA);
+            const dim3 grid(1u << (log_n - p.s - p.log_j), (uint32_t)count), block(1u << (p.s - 2));
+            const size_t lds = sizeof(Fu) << p.s;
+            if (t == 0)
+                hipLaunchKernelGGL(ntt2_strided_kernel, grid, block, lds, s, p);
+            else
+                hipLaunchKernelGGL(ntt2_final_kernel, grid, block, lds, s, p);
+            H2_CHECK(hipGetLastError());
+        }
+        c->timer_end(tid, s);
+        return c->ws_release(s);
+    }
     uint32_t log_m = log_n;
     for (int t = 0; t < P; t++) {
         p.s = S[t];
+        p.stage_tw = p.s == tw.stage_s[0] ? tw.stage[0] : tw.stage[1];
         p.log_m = log_m;
         p.first = (t == 0);
         bool final = (t == P - 1);
@@ -399,7 +654,7 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
             const uint32_t want_j = p.s <= 8 ? 2 : 1;
             p.log_j = log_l < want_j ? log_l : want_j;
         }
-        size_t lds = (((size_t)1 << (p.s + p.log_j)) + ((size_t)1 << p.s) / 2 + 1) * sizeof(Fu);
+        size_t lds = sizeof(Fu) << (p.s + p.log_j);
         uint64_t grid = 1ull << (log_n - p.s - p.log_j);
         if (grid > 0x7fffffffull) {
             set_error("ntt: grid too large");

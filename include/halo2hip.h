@@ -327,6 +327,7 @@ int h2hip_debug_set_reserved_cus(uint32_t k);
 int h2hip_debug_set_msm_fuse_small(int on);
 /* largest log2 tile of an NTT pass (4..10; default 8, 9 beyond 2^24 points) */
 int h2hip_debug_set_ntt_smax(uint32_t v);
+int h2hip_debug_set_ntt_two_pass(uint32_t lo, uint32_t hi);
 /* evaluate_h: programs needing more slots than v use the global-workspace form of the kernels (default 256) */
 int h2hip_debug_set_evalh_max_local_slots(uint32_t v);
 /* evaluate_h: compile a graph as the engine would and report the program's size; needs no GPU */

@@ -146,7 +146,7 @@ def test_ntt_golden(h2, golden, k):
     assert np.array_equal(a, golden[f"ntt_{k}_out"])
 
 
-@pytest.mark.parametrize("k", [11, 12, 13, 15, 16, 17, 18, 20])
+@pytest.mark.parametrize("k", [11, 12, 13, 15, 16, 17, 18, 19, 20, 21])
 def test_ntt_vs_oracle(h2, oracle, k):
     d, _ = oracle.domain_new(2, k)
     a = oracle.gen_scalars(0x5EED0003, 1 << k, num_threads=NT)
@@ -179,7 +179,7 @@ def test_domain_golden(h2, oracle, golden, jk):
     assert np.array_equal(dom.extended_to_coeff(golden[f"ext_{j}_{k}_h_extended"]), golden[f"ext_{j}_{k}_h_coeffs"])
 
 
-@pytest.mark.parametrize("jk", [(4, 10), (4, 14), (3, 12), (2, 11), (4, 17)])
+@pytest.mark.parametrize("jk", [(4, 10), (4, 14), (3, 12), (2, 11), (4, 17), (4, 18), (2, 20)])
 def test_domain_vs_oracle(h2, oracle, jk):
     j, k = jk
     d, _ = oracle.domain_new(j, k)
@@ -208,6 +208,36 @@ def test_ntt_full_size_2p22_roundtrip_and_oracle(h2, oracle):
     h2.ifft_device(da, d.fe("omega_inv"), k, d.fe("ifft_divisor"))
     torch.cuda.synchronize()
     assert np.array_equal(h2.to_numpy_u64(da), a)
+
+
+@pytest.mark.parametrize("k", [18, 19, 20, 21, 22])
+def test_ntt_two_pass_plan_equals_three_pass(h2, oracle, k):
+    """The two plans of ntt.hip (two passes of 2^9..2^11-point tiles, three of 2^6..2^8) give the same limbs for the plain
+    transform, the scaled inverse and the zero-padded coset transform; the tuning hook forces each plan at every size."""
+    import ctypes
+    import torch
+    L = h2.lib()
+    d, _ = oracle.domain_new(4, k - 2)  # extended_k = k
+    assert d.extended_k == k
+    a = h2.gen_scalars_device(77 + k, 1 << k)
+    out = {}
+    try:
+        for plan, (lo, hi) in (("three", (1, 0)), ("two", (18, 22))):
+            L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(lo), ctypes.c_uint32(hi))
+            f = a.clone()
+            h2.ntt_device(f, d.fe("extended_omega"), k)
+            i = a.clone()
+            h2.ifft_device(i, d.fe("extended_omega_inv"), k, d.fe("extended_ifft_divisor"))
+            e = a.clone()
+            h2.coeff_to_extended_device(e, k - 2, k, d.fe("extended_omega"), d.fe("g_coset"), d.fe("g_coset_inv"))
+            b = a.clone()
+            h2.extended_to_coeff_device(b, k, d.fe("extended_omega_inv"), d.fe("extended_ifft_divisor"), d.fe("g_coset"), d.fe("g_coset_inv"))
+            torch.cuda.synchronize()
+            out[plan] = (f, i, e, b)
+    finally:
+        L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(20), ctypes.c_uint32(22))
+    for x, y in zip(out["two"], out["three"]):
+        assert torch.equal(x, y)
 
 
 @pytest.mark.parametrize("k", [6])
@@ -488,7 +518,7 @@ def test_device_resident_column_flow(h2, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", [0, 3, 9, 14, 17])
+@pytest.mark.parametrize("k", [0, 3, 9, 14, 17, 18])
 def test_batched_transforms_equal_single_ones(h2, oracle, k):
     """h2hip_{ntt,ifft,coeff_to_extended}_bn254_fr_batch_device: every column of the batch equals the unbatched entry point
     (which is checked against the oracle above) -- 1-, 2- and 3-pass sizes, five columns"""

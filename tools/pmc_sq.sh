@@ -1,0 +1,17 @@
+#!/bin/bash
+# tools/pmc_sq.sh NAME COUNTERS -- python3 PROGRAM ARGS   one --pmc pass (no trace), per-kernel mean of each counter
+set -e
+name=$1; ctrs=$2; shift; shift; shift
+export TMPDIR=/tmp
+mkdir -p gpurun_out/$name
+rocprofv3 --pmc $ctrs --output-format csv -d gpurun_out/$name -o p -- "$@" > gpurun_out/$name/run.log 2>&1 || { tail -20 gpurun_out/$name/run.log; exit 1; }
+f=$(find gpurun_out/$name -name "*counter_collection.csv" | head -1)
+python3 - "$f" <<'PY'
+import csv, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in acc.items():
+    if "ntt" not in k and "msm" not in k: continue
+    print(k, "  ".join("%s=%.4g (n=%d)" % (c, sum(x) / len(x), len(x)) for c, x in sorted(v.items())))
+PY
