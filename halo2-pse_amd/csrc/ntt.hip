@@ -42,7 +42,8 @@ struct NttPass {
     const Fu* stage_tw;  // this pass's tile twiddles w_R^i, i < R / 2 (every workgroup reads the same few KB: L1 / L2 hits)
     uint64_t in_len;
     uint32_t log_n, log_m, s, log_j, lo_bits;
-    uint32_t first, in_scale, out_scale;
+    uint32_t first, in_scale;
+    uint32_t out_scale;  // 0: none, 1: out3[oi % 3], 2: out3[0] for every output
     uint32_t n_prev;
     uint32_t prev_s[4];
     Fu in3[3], out3[3];  // I-form constants
@@ -72,18 +73,22 @@ __device__ __forceinline__ Fu tw_pow(const NttPass& p, uint64_t e) {
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t k, uint32_t s) { return __brev(k) >> (32 - s); }
 
-// The scale constants are read from the kernel-argument segment itself (the pass descriptor is the first argument of every
-// kernel here): indexing the by-value copy with a lane-dependent residue would send the whole array to scratch.
-__device__ __forceinline__ Fu pick3(size_t field_offset, uint32_t m) {
-    typedef const __attribute__((address_space(4))) int32_t* KernArg;
-    KernArg k = (KernArg)__builtin_amdgcn_kernarg_segment_ptr() + field_offset / 4 + 9 * m;
+// One of three kernel-argument constants by a lane-dependent residue.  The constants stay where kernel arguments live
+// (scalar registers) and the pick is bit-mask arithmetic: a compare-and-select chain is turned by LLVM into an indexed
+// load from a scratch copy of the array, and reading them through a pointer costs a vector load per use.
+__device__ __forceinline__ Fu pick3(const Fu (&c)[3], uint32_t m) {
+    const int32_t m1 = -(int32_t)(m == 1), m2 = -(int32_t)(m == 2);
     Fu r;
 #pragma unroll
-    for (int i = 0; i < 9; i++) r.l[i] = k[i];
+    for (int i = 0; i < 9; i++) r.l[i] = c[0].l[i] ^ ((c[0].l[i] ^ c[1].l[i]) & m1) ^ ((c[0].l[i] ^ c[2].l[i]) & m2);
     return r;
 }
-#define NTT_IN3 offsetof(NttPass, in3)
-#define NTT_OUT3 offsetof(NttPass, out3)
+// the constant of output index oi (< 2^28): 1 (forward transform), one constant (1/n), or one of three by oi mod 3 (coset)
+__device__ __forceinline__ Fu out_const(const NttPass& p, uint64_t oi) {
+    if (p.out_scale == 0) return fu_one_i<FrUA>();
+    if (p.out_scale == 2) return p.out3[0];
+    return pick3(p.out3, (uint32_t)oi % 3u);
+}
 
 // LDS image index of point e.  A point is 9 dwords, so the bank of its dword c is (9 e + c) mod 32: the 32 lanes of a DS
 // access group are conflict-free exactly when their e differ mod 32.  Every access pattern of these kernels varies five
@@ -178,8 +183,8 @@ __device__ __forceinline__ Fu ntt_load(const NttPass& p, const Fe* src, uint64_t
         if (gi >= p.in_len) return fu_zero();
         Fu v = fu_slice(src[gi]);
         if (p.in_scale) {
-            uint32_t m = (uint32_t)(gi % 3);
-            if (m) v = fu_mul<FrUA>(v, pick3(NTT_IN3, m));
+            const uint32_t m = (uint32_t)gi % 3u;  // gi < 2^28
+            if (m) v = fu_mul<FrUA>(v, pick3(p.in3, m));
         }
         return v;
     }
@@ -231,12 +236,10 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_final_kernel(NttPass p) {
     __syncthreads();
     dft_lds(x, p.stage_tw, p.s, p.log_j);
     const uint32_t log_nb = p.log_n - p.s;
-    const Fu one_i = fu_one_i<FrUA>();
     for (uint32_t idx = threadIdx.x; idx < (R << p.log_j); idx += NTT_THREADS) {
         uint32_t k = idx >> p.log_j, jj = idx & (J - 1);
         uint64_t oi = ((uint64_t)k << log_nb) + (g << p.log_j) + jj;
-        Fu c = p.out_scale ? pick3(NTT_OUT3, (uint32_t)(oi % 3)) : one_i;
-        dst[oi] = fu_mul_canon<FrUA>(x[lds_swz((jj << p.s) + k)], c);
+        dst[oi] = fu_mul_canon<FrUA>(x[lds_swz((jj << p.s) + k)], out_const(p, oi));
     }
 }
 
@@ -351,7 +354,6 @@ __global__ void __launch_bounds__(512, 4) ntt2_final_kernel(NttPass p) {
     const uint32_t T = blockDim.x;  // R / 4
     const uint32_t log_nb = p.log_n - p.s;
     const uint64_t v0 = (uint64_t)blockIdx.x << p.log_j;
-    const Fu one_i = fu_one_i<FrUA>();
 #pragma unroll 1
     for (uint32_t c = 0; c < (1u << p.log_j); c++) {
         const uint64_t vb = v0 + c;
@@ -364,8 +366,7 @@ __global__ void __launch_bounds__(512, 4) ntt2_final_kernel(NttPass p) {
         four([&](uint32_t m) __attribute__((always_inline)) {
             const uint64_t k = threadIdx.x + m * T;
             const uint64_t oi = (k << log_nb) + vb;
-            const Fu cst = p.out_scale ? pick3(NTT_OUT3, (uint32_t)(oi % 3)) : one_i;
-            dst[oi] = fu_mul_canon<FrUA>(y[m], cst);
+            dst[oi] = fu_mul_canon<FrUA>(y[m], out_const(p, oi));
         });
     }
 }
@@ -539,7 +540,7 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
     p.in_len = 1ull << log_n;
     if (sc) {
         p.in_scale = sc->in_scale;
-        p.out_scale = sc->out_scale;
+        p.out_scale = !sc->out_scale ? 0 : (memcmp(&sc->out3[0], &sc->out3[1], sizeof(Fe)) == 0 && memcmp(&sc->out3[0], &sc->out3[2], sizeof(Fe)) == 0) ? 2 : 1;
         if (sc->in_len) p.in_len = sc->in_len;
         for (int i = 0; i < 3; i++) {
             p.in3[i] = fu_i_from_fe(sc->in3[i]);
