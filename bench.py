@@ -18,6 +18,7 @@ against 8 TB/s, timed with HIP events on the stream it is launched on; `cpu_base
 oracle's restatement of the reference's rayon path timed on this box's host cores.
 """
 import argparse
+import ctypes
 import json
 import os
 import subprocess
@@ -401,10 +402,20 @@ def main():
         h2.bases_pin(bs)
         hp["msm_2p%d_pinned_ms" % args.log_n] = host_ms(lambda: h2.best_multiexp(sc, bs))
         h2.bases_unpin(bs)
+        # the same unpatched call with HALO2_HIP_LAZY_PIN=2 (set here through the library's hook): the second sighting pins the array
+        h2.lib().h2hip_debug_set_lazy_pin(ctypes.c_uint32(2))
+        try:
+            hp["msm_2p%d_lazy_pin_ms" % args.log_n] = host_ms(lambda: h2.best_multiexp(sc, bs))
+        finally:
+            h2.lib().h2hip_debug_set_lazy_pin(ctypes.c_uint32(0))
+            try:
+                h2.bases_unpin(bs)
+            except h2.H2HipError:
+                pass
         dk = h2.EvaluationDomain.new(2, args.ntt_log_n)
         a = h2.to_numpy_u64(h2.gen_scalars_device(3, 1 << args.ntt_log_n, device=dev)).copy()
         hp["ntt_2p%d_ms" % args.ntt_log_n] = host_ms(lambda: h2.best_fft(a, dk.omega, args.ntt_log_n), reps=3)
-        hp["note"] = "h2hip_msm_bn254 / h2hip_ntt_bn254_fr with host pointers: the scalars (and, unpinned, the bases) cross PCIe inside the call"
+        hp["note"] = "h2hip_msm_bn254 / h2hip_ntt_bn254_fr with host pointers: the scalars (and, unpinned, the bases) cross PCIe inside the call; lazy_pin = no h2hip_bases_pin call, HALO2_HIP_LAZY_PIN=2"
         sizes["host_pointer"] = hp
         del sc, bs, a
         sys.path.insert(0, os.path.join(ROOT, "tools"))

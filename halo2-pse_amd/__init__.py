@@ -58,6 +58,7 @@ def lib():
         L.h2hip_get_msm_window_fixed_base.argtypes = [ctypes.c_size_t]
         L.h2hip_msm_min_n.restype = ctypes.c_size_t
         L.h2hip_ntt_min_log_n.restype = ctypes.c_uint32
+        L.h2hip_lazy_pin_after.restype = ctypes.c_uint32
         # release streams, workspaces and worker threads while the HIP runtime is still alive (a profiler's own
         # finalisation otherwise meets them in the static destructors at process exit)
         import atexit
@@ -506,6 +507,11 @@ def msm_min_n():
 
 def ntt_min_log_n():
     return int(lib().h2hip_ntt_min_log_n())
+
+
+def lazy_pin_after():
+    """HALO2_HIP_LAZY_PIN: unpinned sightings of a host bases array after which the library pins it itself (0 = never)"""
+    return int(lib().h2hip_lazy_pin_after())
 
 
 def profile_enable(on=True):

@@ -248,6 +248,7 @@ struct Config {
     size_t table_max_bytes = (size_t)160 << 30;  // HALO2_HIP_TABLE_MAX_GB: largest window table built at pin time
     bool allow_dup = false;                    // HALO2_HIP_ALLOW_DUPLICATE_DEVICES=1: rehearsal on a one-GPU box
     bool roctx = false;                        // HALO2_HIP_ROCTX=1: roctx range around every entry point
+    uint32_t lazy_pin_after = 0;               // HALO2_HIP_LAZY_PIN=k: a host bases array seen k times unpinned is pinned by the library
 };
 static Config g_cfg;
 
@@ -271,6 +272,7 @@ static void read_config() {
     if (env_u64("HALO2_HIP_TABLE_MAX_GB", &v)) c.table_max_bytes = (size_t)v << 30;
     if (env_u64("HALO2_HIP_ALLOW_DUPLICATE_DEVICES", &v)) c.allow_dup = v != 0;
     if (env_u64("HALO2_HIP_ROCTX", &v)) c.roctx = v != 0;
+    if (env_u64("HALO2_HIP_LAZY_PIN", &v)) c.lazy_pin_after = (uint32_t)v;
     if (env_u64("HALO2_HIP_MSM_WINDOW", &v) && v >= 2 && v <= 24) msm_set_window((uint32_t)v);
     const char* g = getenv("HALO2_HIP_GATHER");
     if (g && !strcmp(g, "host")) c.gather_rccl = false;
@@ -717,6 +719,10 @@ static const MsmTable* pinned_table(Ctx* c, const void* key, size_t n, const Aff
 
 using namespace h2;
 
+static void lazy_forget(const void* key);
+static void lazy_reset();
+static void lazy_pin_consider(const uint64_t* bases_xy, size_t n);
+
 extern "C" {
 
 int h2hip_init(const int* device_ids, int n_devices) { return do_init(device_ids, n_devices); }
@@ -744,6 +750,7 @@ void h2hip_shutdown(void) {
         if (i) delete g_devs[i];
     }
     g_devs.clear();
+    lazy_reset();
 }
 
 const char* h2hip_last_error(void) { return g_err; }
@@ -872,6 +879,7 @@ static int msm_host_common(const uint64_t* const* scalars, const uint64_t* bases
     // a pinned entry whose fingerprint no longer matches the caller's array is stale (the allocation was freed and
     // reused): drop it on every device and fall back to uploading
     pinned_validate(bases_xy, n);
+    lazy_pin_consider(bases_xy, n);
     const int nd = (int)g_devs.size();
     if (nd == 1 || n < g_cfg.multi_gpu_min_n) {
         std::vector<XYZZ> r(count);
@@ -1014,13 +1022,8 @@ static void pin_sample(const uint64_t* bases_xy, size_t n, uint8_t* out) {
     }
 }
 
-int h2hip_bases_pin(const uint64_t* bases_xy, size_t n) {
-    if (!bases_xy || !n) {
-        set_error("bases_pin: null/empty");
-        return H2HIP_EINVAL;
-    }
-    Entry en("h2hip_bases_pin");
-    if (en.rc) return en.rc;
+// pin a host array on every device (its contiguous share each): the body of h2hip_bases_pin, also reached by the lazy cache
+static int pin_host_everywhere(const uint64_t* bases_xy, size_t n) {
     uint8_t sample[H2_PIN_SAMPLES * 64];
     pin_sample(bases_xy, n, sample);
     const int nd = (int)g_devs.size();
@@ -1032,6 +1035,108 @@ int h2hip_bases_pin(const uint64_t* bases_xy, size_t n) {
     });
     if (rc) (void)unpin_everywhere((const void*)bases_xy);
     return rc;
+}
+
+int h2hip_bases_pin(const uint64_t* bases_xy, size_t n) {
+    if (!bases_xy || !n) {
+        set_error("bases_pin: null/empty");
+        return H2HIP_EINVAL;
+    }
+    Entry en("h2hip_bases_pin");
+    if (en.rc) return en.rc;
+    lazy_forget((const void*)bases_xy);  // an explicit pin is the caller's to unpin
+    return pin_host_everywhere(bases_xy, n);
+}
+
+// ---- optional lazy cache (HALO2_HIP_LAZY_PIN=k, off by default) ----------------------------------------------------------
+// The unpatched drop-in calls best_multiexp(coeffs, &params.g[..]) with no handle in the signature and uploads 64 B per
+// point every time.  With the knob set, a host array that arrives unpinned for the k-th time with the same address and
+// the same sampled points is pinned by the library itself (window table included).  From then on it is an ordinary
+// pinned entry: every lookup re-checks the 16 sampled points and a mismatch drops it, so a freed and reused
+// allocation costs an upload, not a wrong commitment; what the samples cannot see is a caller that rewrites part of a
+// live array in place -- ParamsKZG never does (downsize truncates g and builds a new g_lagrange, kzg/commitment.rs:267-275),
+// which is why the knob is opt-in.  At most H2_LAZY_MAX arrays are held this way, the least recently used goes first.
+#define H2_LAZY_MAX 4
+struct LazySeen {
+    const void* key;
+    size_t n;
+    uint32_t count;
+    uint8_t sample[H2_PIN_SAMPLES * 64];
+};
+static std::vector<LazySeen> g_lazy_seen;        // candidates, at most 8, oldest first
+static std::vector<const void*> g_lazy_pinned;   // arrays this cache pinned, least recently used first
+
+static void lazy_reset() {
+    g_lazy_seen.clear();
+    g_lazy_pinned.clear();
+}
+
+static void lazy_forget(const void* key) {
+    for (size_t i = 0; i < g_lazy_seen.size(); i++)
+        if (g_lazy_seen[i].key == key) {
+            g_lazy_seen.erase(g_lazy_seen.begin() + (long)i);
+            break;
+        }
+    for (size_t i = 0; i < g_lazy_pinned.size(); i++)
+        if (g_lazy_pinned[i] == key) {
+            g_lazy_pinned.erase(g_lazy_pinned.begin() + (long)i);
+            break;
+        }
+}
+
+// called by the host-pointer MSMs after pinned_validate; pins `bases_xy` when it has been seen often enough
+static void lazy_pin_consider(const uint64_t* bases_xy, size_t n) {
+    if (!g_cfg.lazy_pin_after || n < 1024) return;
+    const void* key = (const void*)bases_xy;
+    if (ctx()->pinned.count(key)) {  // in use: refresh its place in the LRU order if it is ours
+        for (size_t i = 0; i + 1 < g_lazy_pinned.size(); i++)
+            if (g_lazy_pinned[i] == key) {
+                g_lazy_pinned.erase(g_lazy_pinned.begin() + (long)i);
+                g_lazy_pinned.push_back(key);
+                break;
+            }
+        return;
+    }
+    for (size_t i = 0; i < g_lazy_pinned.size(); i++)  // ours once, dropped since by a failed validation
+        if (g_lazy_pinned[i] == key) {
+            g_lazy_pinned.erase(g_lazy_pinned.begin() + (long)i);
+            break;
+        }
+    uint8_t sample[H2_PIN_SAMPLES * 64];
+    pin_sample(bases_xy, n, sample);
+    LazySeen* e = nullptr;
+    for (auto& x : g_lazy_seen)
+        if (x.key == key) e = &x;
+    if (!e) {
+        if (g_lazy_seen.size() >= 8) g_lazy_seen.erase(g_lazy_seen.begin());
+        g_lazy_seen.push_back(LazySeen());
+        e = &g_lazy_seen.back();
+        e->key = key;
+        e->count = 0;
+    }
+    if (e->count && (e->n != n || memcmp(e->sample, sample, sizeof(sample)) != 0)) e->count = 0;  // another array at this address
+    e->n = n;
+    memcpy(e->sample, sample, sizeof(sample));
+    if (++e->count < g_cfg.lazy_pin_after) return;
+    lazy_forget(key);
+    while (g_lazy_pinned.size() >= H2_LAZY_MAX) {
+        (void)unpin_everywhere(g_lazy_pinned.front());
+        g_lazy_pinned.erase(g_lazy_pinned.begin());
+    }
+    if (pin_host_everywhere(bases_xy, n) == 0) g_lazy_pinned.push_back(key);  // a failed pin (no room for the table) just leaves the upload path
+}
+
+uint32_t h2hip_lazy_pin_after(void) {
+    (void)ensure_init();
+    return g_cfg.lazy_pin_after;
+}
+
+// test hook: the knob without the environment
+int h2hip_debug_set_lazy_pin(uint32_t after) {
+    Entry en("h2hip_debug_set_lazy_pin");
+    if (en.rc) return en.rc;
+    g_cfg.lazy_pin_after = after;
+    return 0;
 }
 
 int h2hip_bases_pin_device(const void* d_bases_xy, size_t n, void* stream) {
@@ -1048,6 +1153,7 @@ int h2hip_bases_pin_device(const void* d_bases_xy, size_t n, void* stream) {
 int h2hip_bases_unpin(const void* bases_xy) {
     Entry en("h2hip_bases_unpin");
     if (en.rc) return en.rc;
+    lazy_forget(bases_xy);
     if (!unpin_everywhere(bases_xy)) {
         set_error("bases_unpin: pointer was not pinned");
         return H2HIP_EINVAL;

@@ -28,7 +28,9 @@
  * how the devices' 96-byte partials meet; HALO2_HIP_MSM_WINDOW; HALO2_HIP_FIXED_BASE=0 and
  * HALO2_HIP_TABLE_MAX_GB for h2hip_bases_pin's window tables; HALO2_HIP_MSM_MIN_N /
  * HALO2_HIP_NTT_MIN_LOGN thresholds the Rust shim reads back through h2hip_msm_min_n() /
- * h2hip_ntt_min_log_n(); HALO2_HIP_ROCTX=1 roctx ranges around every entry point.
+ * h2hip_ntt_min_log_n(); HALO2_HIP_ROCTX=1 roctx ranges around every entry point;
+ * HALO2_HIP_LAZY_PIN=k (default 0 = off) lets the library pin a host bases array by itself once a
+ * host-pointer MSM has seen it k times (see h2hip_bases_pin).
  */
 #ifndef HALO2HIP_H
 #define HALO2HIP_H
@@ -86,6 +88,12 @@ int h2hip_msm_bn254(const uint64_t* scalars, const uint64_t* bases_xy, size_t n,
  * The cache is safe against stale pointers: every lookup compares 16 sampled points of the caller's array
  * with the ones seen at pin time and falls back to a plain upload (dropping the entry) on a mismatch. */
 int h2hip_bases_pin(const uint64_t* bases_xy, size_t n);
+/* The lazy cache (HALO2_HIP_LAZY_PIN=k): for the unpatched two-line drop-in, whose best_multiexp(coeffs, bases) has no
+ * handle in its signature.  A host array that reaches h2hip_msm_bn254[_batch] unpinned for the k-th time with the same
+ * address, length and sampled points is pinned as above by the library (at most 4 such arrays, least recently used
+ * dropped first; h2hip_bases_unpin removes one, h2hip_shutdown all).  Lookups validate it like any pinned entry.  What the
+ * samples cannot see is a caller rewriting part of a live array in place; ParamsKZG never does, hence opt-in. */
+uint32_t h2hip_lazy_pin_after(void);
 /* the same for points that already live in HBM (keyed by the device pointer, used by the _device MSMs);
  * the points are copied, the caller's buffer is not referenced after the call returns */
 int h2hip_bases_pin_device(const void* d_bases_xy, size_t n, void* stream);
@@ -327,6 +335,7 @@ int h2hip_debug_set_reserved_cus(uint32_t k);
 int h2hip_debug_set_msm_fuse_small(int on);
 /* largest log2 tile of an NTT pass (4..10; default 8, 9 beyond 2^24 points) */
 int h2hip_debug_set_ntt_smax(uint32_t v);
+int h2hip_debug_set_lazy_pin(uint32_t after);
 int h2hip_debug_set_ntt_two_pass(uint32_t lo, uint32_t hi);
 /* evaluate_h: programs needing more slots than v use the global-workspace form of the kernels (default 256) */
 int h2hip_debug_set_evalh_max_local_slots(uint32_t v);

@@ -378,3 +378,60 @@ dist.destroy_process_group()
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert "RESULT True" in r.stdout
+
+
+def test_lazy_cache_pins_after_k_sightings_and_stays_correct(h2, oracle):
+    """HALO2_HIP_LAZY_PIN (here through the test hook): the unpatched drop-in passes the same &params.g[..] to every
+    best_multiexp.  The k-th unpinned sighting of an array pins it (window table included); results stay the oracle's before,
+    at and after that call; a reused allocation is caught by the fingerprint; at most four arrays are held, LRU first out."""
+    import ctypes
+    L = h2.lib()
+    n = 1 << 13
+    bs = oracle.gen_points(5100, n, num_threads=NT)
+    cols = [oracle.gen_scalars(5110 + j, n, num_threads=NT) for j in range(4)]
+    want = [oracle.g1_to_affine(oracle.best_multiexp(c, bs, NT)) for c in cols]
+
+    def pinned(a):
+        try:
+            return h2.bases_pinned_info(a)
+        except h2.H2HipError:
+            return None
+
+    assert h2.lazy_pin_after() == 0  # off unless asked for
+    assert L.h2hip_debug_set_lazy_pin(ctypes.c_uint32(2)) == 0
+    others = []
+    try:
+        assert h2.lazy_pin_after() == 2
+        assert np.array_equal(aff(h2, h2.best_multiexp(cols[0], bs)), want[0])
+        assert pinned(bs) is None                      # seen once
+        assert np.array_equal(aff(h2, h2.best_multiexp(cols[1], bs)), want[1])
+        info = pinned(bs)                              # second sighting: pinned before this MSM ran
+        assert info is not None and info[0] == n and info[1] == h2.get_msm_window_fixed_base(n) and info[2] > 0
+        assert np.array_equal(aff(h2, h2.best_multiexp(cols[2], bs)), want[2])
+        # a prefix of the array (commit of a shorter polynomial) uses the same entry
+        m = n - 100
+        assert np.array_equal(aff(h2, h2.best_multiexp(cols[3][:m], bs[:m])), oracle.g1_to_affine(oracle.best_multiexp(cols[3][:m], bs[:m], NT)))
+        assert pinned(bs) is not None
+        # the allocation is "reused": same address, other points -> the entry is dropped, the result is the new array's
+        bs[:] = oracle.gen_points(5200, n, num_threads=NT)
+        assert np.array_equal(aff(h2, h2.best_multiexp(cols[0], bs)), oracle.g1_to_affine(oracle.best_multiexp(cols[0], bs, NT)))
+        assert pinned(bs) is None                      # first sighting of the new content
+        assert np.array_equal(aff(h2, h2.best_multiexp(cols[1], bs)), oracle.g1_to_affine(oracle.best_multiexp(cols[1], bs, NT)))
+        assert pinned(bs) is not None
+        # five more arrays: at most four stay pinned, the least recently used (bs) goes first
+        for j in range(5):
+            o = oracle.gen_points(5300 + j, 2048, num_threads=NT)
+            others.append(o)
+            sc = oracle.gen_scalars(5400 + j, 2048, num_threads=NT)
+            for _ in range(2):
+                assert np.array_equal(aff(h2, h2.best_multiexp(sc, o)), oracle.g1_to_affine(oracle.best_multiexp(sc, o, NT)))
+        held = [o for o in [bs] + others if pinned(o) is not None]
+        assert len(held) == 4 and pinned(bs) is None and pinned(others[0]) is None and pinned(others[4]) is not None
+        # an explicit unpin removes a lazily pinned array like any other
+        h2.bases_unpin(others[4])
+        assert pinned(others[4]) is None
+    finally:
+        L.h2hip_debug_set_lazy_pin(ctypes.c_uint32(0))
+        for o in [bs] + others:
+            if pinned(o) is not None:
+                h2.bases_unpin(o)
