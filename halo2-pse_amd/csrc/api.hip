@@ -29,6 +29,7 @@ void msm_set_fuse_limits(size_t entries, size_t max_n);
 void msm_set_rowcol(uint64_t lanes, bool use_asm);
 void ntt_set_smax(uint32_t v);
 void ntt_set_two_pass(uint32_t lo, uint32_t hi);
+void ntt_set_full_twiddle_budget(uint64_t bytes);
 void msm_set_reserved_cus(uint32_t k);
 uint32_t msm_get_reserved_cus();
 uint32_t msm_get_window(size_t n);
@@ -273,6 +274,7 @@ static void read_config() {
     if (env_u64("HALO2_HIP_ALLOW_DUPLICATE_DEVICES", &v)) c.allow_dup = v != 0;
     if (env_u64("HALO2_HIP_ROCTX", &v)) c.roctx = v != 0;
     if (env_u64("HALO2_HIP_LAZY_PIN", &v)) c.lazy_pin_after = (uint32_t)v;
+    if (env_u64("HALO2_HIP_NTT_TWIDDLE_MB", &v)) ntt_set_full_twiddle_budget(v << 20);
     if (env_u64("HALO2_HIP_MSM_WINDOW", &v) && v >= 2 && v <= 24) msm_set_window((uint32_t)v);
     const char* g = getenv("HALO2_HIP_GATHER");
     if (g && !strcmp(g, "host")) c.gather_rccl = false;
@@ -627,11 +629,7 @@ static void release_ctx(Ctx* c) {
     if (c->ready) (void)hipDeviceSynchronize();
     c->timers_collect();
     c->timers.clear();
-    for (auto& kv : c->twiddles) {
-        (void)hipFree(kv.second.lo);
-        (void)hipFree(kv.second.hi);
-    }
-    c->twiddles.clear();
+    ntt_twiddles_free(c);
     for (auto& kv : c->pinned) (void)hipFree(kv.second.d);
     c->pinned.clear();
     c->ntt_ws.release();
@@ -1720,6 +1718,12 @@ int h2hip_debug_set_ntt_smax(uint32_t v) {
 }
 
 // tuning hook: sizes 2^lo..2^hi (within 18..22) take the two-pass plan; hi < lo turns it off
+// tuning hook: HBM (bytes per device) the two-pass plan's full inter-pass twiddle tables may take; 0 = two-level table only
+int h2hip_debug_set_ntt_twiddle_budget(uint64_t bytes) {
+    ntt_set_full_twiddle_budget(bytes);
+    return 0;
+}
+
 int h2hip_debug_set_ntt_two_pass(uint32_t lo, uint32_t hi) {
     ntt_set_two_pass(lo, hi);
     return 0;

@@ -59,6 +59,9 @@ struct TwiddleTable {
     // two-pass plan (ntt.hip): the tile DFT's own twiddles w_R^i, i < R / 2, for R = 2^stage_s[t]
     Fu* stage[2] = {nullptr, nullptr};
     uint32_t stage_s[2] = {0, 0};
+    // two-pass plan: the inter-pass twiddles omega^(k * lo) themselves, [lo][k] (2^log_n entries of 36 B), when the budget allows
+    Fu* full = nullptr;
+    uint32_t full_s = 0;  // k < 2^full_s
 };
 
 // Fixed-base window table of a pinned base array (msm.hip): row j (of `stride` points) = 2^(c j) * P, j < W
@@ -102,6 +105,7 @@ struct Ctx {
     size_t stage_off = 0;
     int stage_h2d(void* d_dst, const void* h_src, size_t bytes, hipStream_t s);
     std::map<TwiddleKey, TwiddleTable> twiddles;
+    size_t tw_full_bytes = 0;  // HBM held by the two-pass plan's full inter-pass twiddle tables
     std::map<const void*, PinnedBases> pinned;
     // profiling
     bool profiling = false;        // every stage bracketed by a pair of events (each record costs the stream ~10 us)
@@ -143,6 +147,7 @@ struct NttScale {
 };
 // d_src (optional): the first pass reads its input there instead of d_data (which is then output only); with
 // sc->in_len set only d_src[0 .. in_len) is read
+void ntt_twiddles_free(Ctx* c);
 int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttScale* sc, hipStream_t s, const Fe* d_src = nullptr);
 
 int ntt_device_batch(Ctx* c, Fe* const* h_datas, const Fe* const* h_srcs, size_t count, const Fe& omega, uint32_t log_n, const NttScale* sc,

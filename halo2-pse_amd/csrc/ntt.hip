@@ -39,6 +39,7 @@ struct NttPass {
     Fe* dst;
     const Fu* tw_lo;
     const Fu* tw_hi;
+    const Fu* tw_full;   // two-pass plan, pass 1: omega^(k * lo) at [lo << s | k], or null (tw_pow then combines the two-level table)
     const Fu* stage_tw;  // this pass's tile twiddles w_R^i, i < R / 2 (every workgroup reads the same few KB: L1 / L2 hits)
     uint64_t in_len;
     uint32_t log_n, log_m, s, log_j, lo_bits;
@@ -341,7 +342,8 @@ __global__ void __launch_bounds__(512, 4) ntt2_strided_kernel(NttPass p) {
         dft_col(x, p.stage_tw, p.s, v, y);
         four([&](uint32_t m) __attribute__((always_inline)) {
             const uint64_t k = threadIdx.x + m * T;
-            dst[(k << log_l) + lo] = fu_mul_canon<FrUA>(y[m], tw_pow(p, k * lo));  // w_N^(k * lo)
+            const Fu w = p.tw_full ? p.tw_full[(lo << p.s) + k] : tw_pow(p, k * lo);  // w_N^(k * lo)
+            dst[(k << log_l) + lo] = fu_mul_canon<FrUA>(y[m], w);
         });
     }
 }
@@ -371,6 +373,14 @@ __global__ void __launch_bounds__(512, 4) ntt2_final_kernel(NttPass p) {
     }
 }
 
+// the two-pass plan's inter-pass twiddles as one table: entry (lo << s | k) = omega^(k * lo)
+__global__ void __launch_bounds__(256) full_twiddle_build_kernel(NttPass p, Fu* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> p.log_n) return;
+    const uint64_t k = i & ((1ull << p.s) - 1), lo = i >> p.s;
+    out[i] = fu_norm(tw_pow(p, k * lo));
+}
+
 __global__ void stage_twiddle_build_kernel(Fe omega, uint32_t shift, uint32_t count, Fu* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) out[i] = fu_i_from_fe(fe_pow_u64<FrP>(omega, (uint64_t)i << shift));
@@ -394,6 +404,23 @@ __global__ void twiddle_build_kernel(Fe omega, Fu* lo, uint32_t n_lo, Fu* hi, ui
     }
 }
 
+// every table of the twiddle cache (the caller has made sure no kernel still reads them)
+void ntt_twiddles_free(Ctx* c) {
+    for (auto& kv : c->twiddles) {
+        TwiddleTable& t = kv.second;
+        (void)hipFree(t.lo);
+        (void)hipFree(t.hi);
+        if (t.stage[1] != t.stage[0]) (void)hipFree(t.stage[1]);
+        (void)hipFree(t.stage[0]);
+        (void)hipFree(t.full);
+    }
+    c->twiddles.clear();
+    c->tw_full_bytes = 0;
+}
+
+static uint64_t g_ntt_full_budget = (uint64_t)1 << 30;  // HALO2_HIP_NTT_TWIDDLE_MB: HBM the full inter-pass tables may take per device
+void ntt_set_full_twiddle_budget(uint64_t bytes) { g_ntt_full_budget = bytes; }
+
 static int get_twiddles(Ctx* c, const Fe& omega, uint32_t log_n, hipStream_t s, TwiddleTable* out) {
     TwiddleKey key;
     for (int i = 0; i < 8; i++) key.omega[i] = omega.l[i];
@@ -414,13 +441,7 @@ static int get_twiddles(Ctx* c, const Fe& omega, uint32_t log_n, hipStream_t s, 
     H2_CHECK(hipStreamSynchronize(s));  // built once per (omega, log_n); later calls may use another stream
     if (c->twiddles.size() >= 64) {  // bounded cache: a prover uses a handful of domains
         H2_CHECK(hipDeviceSynchronize());
-        for (auto& kv : c->twiddles) {
-            (void)hipFree(kv.second.lo);
-            (void)hipFree(kv.second.hi);
-            if (kv.second.stage[1] != kv.second.stage[0]) (void)hipFree(kv.second.stage[1]);
-            (void)hipFree(kv.second.stage[0]);
-        }
-        c->twiddles.clear();
+        ntt_twiddles_free(c);
     }
     c->twiddles[key] = t;
     *out = t;
@@ -460,6 +481,41 @@ static int get_stage_twiddles(Ctx* c, const Fe& omega, uint32_t log_n, uint32_t 
         H2_CHECK(hipStreamSynchronize(s));  // built once per domain; later calls may use another stream
         t.stage[k] = d;
         t.stage_s[k] = want[k];
+    }
+    *out = t;
+    return 0;
+}
+
+// The two-pass plan's inter-pass twiddles omega^(k * lo) as a table of 2^log_n entries (38 MB at 2^20, 75 MB at 2^21), built once per domain
+// while the budget lasts: it replaces the multiplication that combines the two-level table, one of a pass's seven per element,
+// by a 36-byte coalesced read.  `p` carries the two-level table and s = the first pass's radix.  Leaves t->full null when the
+// budget is spent: the kernel then falls back to tw_pow.
+static int get_full_twiddles(Ctx* c, const Fe& omega, const NttPass& p, hipStream_t s, TwiddleTable* out) {
+    TwiddleKey key;
+    for (int i = 0; i < 8; i++) key.omega[i] = omega.l[i];
+    key.log_n = p.log_n;
+    auto it = c->twiddles.find(key);
+    if (it == c->twiddles.end()) return 0;
+    TwiddleTable& t = it->second;
+    const size_t bytes = sizeof(Fu) << p.log_n;
+    if (t.full && t.full_s != p.s) {  // the plan changed under a tuning hook
+        H2_CHECK(hipDeviceSynchronize());
+        (void)hipFree(t.full);
+        t.full = nullptr;
+        c->tw_full_bytes -= bytes;
+    }
+    if (!t.full && c->tw_full_bytes + bytes <= g_ntt_full_budget) {
+        Fu* d = nullptr;
+        if (hipMalloc((void**)&d, bytes) == hipSuccess) {
+            hipLaunchKernelGGL(full_twiddle_build_kernel, dim3((uint32_t)(((uint64_t)1 << p.log_n) / 256)), dim3(256), 0, s, p, d);
+            H2_CHECK(hipGetLastError());
+            H2_CHECK(hipStreamSynchronize(s));
+            t.full = d;
+            t.full_s = p.s;
+            c->tw_full_bytes += bytes;
+        } else {
+            (void)hipGetLastError();  // no room: not an error, the two-level table still serves
+        }
     }
     *out = t;
     return 0;
@@ -615,12 +671,17 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
             H2_CHECK(hipFuncSetAttribute((const void*)ntt2_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
             g_ntt2_attr[c->device] = true;
         }
+        p.s = S[0];
+        // up to 2^21 points the table (36 B per point), the data and the workspace share the 256 MB Infinity Cache: -6 %; at 2^22 they
+        // no longer do and the table costs 7 % instead
+        if (log_n <= 21 && (rc = get_full_twiddles(c, omega, p, s, &tw))) return rc;
         p.log_m = log_n;
         p.log_j = 1;  // two columns (64-byte rows): four halve the workgroups and measure 6 % slower at 2^22, 24 % at 2^20
         for (int t = 0; t < 2; t++) {
             p.s = S[t];
             p.first = (t == 0);
             p.stage_tw = tw.stage[t];
+            p.tw_full = t == 0 ? tw.full : nullptr;
             bind(t == 0 ? FIRST : WS, t == 0 ? WS : DATA);
             const dim3 grid(1u << (log_n - p.s - p.log_j), (uint32_t)count), block(1u << (p.s - 2));
             const size_t lds = sizeof(Fu) << p.s;

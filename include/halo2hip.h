@@ -29,6 +29,8 @@
  * HALO2_HIP_TABLE_MAX_GB for h2hip_bases_pin's window tables; HALO2_HIP_MSM_MIN_N /
  * HALO2_HIP_NTT_MIN_LOGN thresholds the Rust shim reads back through h2hip_msm_min_n() /
  * h2hip_ntt_min_log_n(); HALO2_HIP_ROCTX=1 roctx ranges around every entry point;
+ * HALO2_HIP_NTT_TWIDDLE_MB (default 1024) HBM per device for the full inter-pass twiddle tables of 2^20- and 2^21-point
+ * transforms (36 bytes per point and domain; without room the two-level table serves, one multiplication more per point);
  * HALO2_HIP_LAZY_PIN=k (default 0 = off) lets the library pin a host bases array by itself once a
  * host-pointer MSM has seen it k times (see h2hip_bases_pin).
  */
@@ -337,6 +339,7 @@ int h2hip_debug_set_msm_fuse_small(int on);
 int h2hip_debug_set_ntt_smax(uint32_t v);
 int h2hip_debug_set_lazy_pin(uint32_t after);
 int h2hip_debug_set_ntt_two_pass(uint32_t lo, uint32_t hi);
+int h2hip_debug_set_ntt_twiddle_budget(uint64_t bytes);
 /* evaluate_h: programs needing more slots than v use the global-workspace form of the kernels (default 256) */
 int h2hip_debug_set_evalh_max_local_slots(uint32_t v);
 /* evaluate_h: compile a graph as the engine would and report the program's size; needs no GPU */

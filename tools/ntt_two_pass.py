@@ -1,4 +1,5 @@
-"""The two plans of ntt.hip on one box: three passes of 2^6..2^8-point tiles against two of 2^9..2^11 (same limbs; ms per transform).
+"""The two plans of ntt.hip on one box: three passes of 2^6..2^8-point tiles against two of 2^9..2^11, with and
+without the full inter-pass twiddle table (same limbs; ms per transform).
 KS=18,20,22 picks the sizes."""
 import ctypes, os, sys
 sys.path.insert(0, "/root/repo")
@@ -21,12 +22,13 @@ for k in [int(v) for v in os.environ.get("KS", "18,19,20,21,22").split(",")]:
     d = h2.EvaluationDomain.new(2, k)
     da = h2.gen_scalars_device(3, 1 << k)
     out = {}
-    for name, (lo, hi) in (("three", (1, 0)), ("two", (18, 22))):
+    for name, (lo, hi, budget) in (("three", (1, 0, 0)), ("two", (18, 22, 0)), ("two+table", (18, 22, 1 << 30))):
         lib.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(lo), ctypes.c_uint32(hi))
+        lib.h2hip_debug_set_ntt_twiddle_budget(ctypes.c_uint64(budget))
         x = da.clone(); h2.ntt_device(x, d.omega, k)
         y = da.clone(); h2.ntt_device(y, d.omega_inv, k)
         torch.cuda.synchronize()
         out[name] = (x, y, timed(lambda: h2.ntt_device(x, d.omega, k), 20))
     lib.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(20), ctypes.c_uint32(22))
-    ok = torch.equal(out["two"][0], out["three"][0]) and torch.equal(out["two"][1], out["three"][1])
+    ok = all(torch.equal(v[0], out["three"][0]) and torch.equal(v[1], out["three"][1]) for v in out.values())
     print("2^%d: " % k + "  ".join("%s %.4f" % (n, v[2]) for n, v in out.items()) + "  same=%s" % ok, flush=True)
