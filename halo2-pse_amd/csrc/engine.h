@@ -59,9 +59,10 @@ struct TwiddleTable {
     // two-pass plan (ntt.hip): the tile DFT's own twiddles w_R^i, i < R / 2, for R = 2^stage_s[t]
     Fu* stage[2] = {nullptr, nullptr};
     uint32_t stage_s[2] = {0, 0};
-    // two-pass plan: the inter-pass twiddles omega^(k * lo) themselves, [lo][k] (2^log_n entries of 36 B), when the budget allows
-    Fu* full = nullptr;
-    uint32_t full_s = 0;  // k < 2^full_s
+    // the inter-pass twiddles of a pass as one table, when the budget allows (ntt.hip get_full_twiddles): slot 0 the two-pass plan's
+    // pass 1, slots 1..3 strided pass 0..2 of the other plan; tag = log_m << 8 | s
+    Fu* full[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t full_tag[4] = {0, 0, 0, 0};
 };
 
 // Fixed-base window table of a pinned base array (msm.hip): row j (of `stride` points) = 2^(c j) * P, j < W

@@ -39,7 +39,8 @@ struct NttPass {
     Fe* dst;
     const Fu* tw_lo;
     const Fu* tw_hi;
-    const Fu* tw_full;   // two-pass plan, pass 1: omega^(k * lo) at [lo << s | k], or null (tw_pow then combines the two-level table)
+    const Fu* tw_full;   // this pass's inter-pass twiddles as one table -- two-pass plan: omega^(k lo) at [lo << s | k]; strided passes of the
+                         // other plan: w_M^(k lo) at [k << log_l | lo] -- or null (tw_pow then combines the two-level table: one multiplication more)
     const Fu* stage_tw;  // this pass's tile twiddles w_R^i, i < R / 2 (every workgroup reads the same few KB: L1 / L2 hits)
     uint64_t in_len;
     uint32_t log_n, log_m, s, log_j, lo_bits;
@@ -214,7 +215,8 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_strided_kernel(NttPass p) {
         uint32_t k = idx >> p.log_j, jj = idx & (J - 1);
         uint64_t lo = lo0 + jj;
         uint64_t e = ((uint64_t)k * lo) << (p.log_n - p.log_m);  // w_M^(k*lo) = omega^((N/M)*k*lo)
-        dst[base + ((uint64_t)k << log_l) + lo] = fu_mul_canon<FrUA>(x[lds_swz((jj << p.s) + k)], tw_pow(p, e));
+        const Fu w = p.tw_full ? p.tw_full[((uint64_t)k << log_l) + lo] : tw_pow(p, e);
+        dst[base + ((uint64_t)k << log_l) + lo] = fu_mul_canon<FrUA>(x[lds_swz((jj << p.s) + k)], w);
     }
 }
 
@@ -378,7 +380,16 @@ __global__ void __launch_bounds__(256) full_twiddle_build_kernel(NttPass p, Fu* 
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >> p.log_n) return;
     const uint64_t k = i & ((1ull << p.s) - 1), lo = i >> p.s;
-    out[i] = fu_norm(tw_pow(p, k * lo));
+    out[i] = tw_pow(p, k * lo);
+}
+
+// a strided pass's inter-pass twiddles as one table: entry (k << log_l | lo) = w_M^(k * lo), M = 2^log_m = R * L
+__global__ void __launch_bounds__(256) pass_twiddle_build_kernel(NttPass p, Fu* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> p.log_m) return;
+    const uint32_t log_l = p.log_m - p.s;
+    const uint64_t lo = i & ((1ull << log_l) - 1), k = i >> log_l;
+    out[i] = tw_pow(p, (k * lo) << (p.log_n - p.log_m));
 }
 
 __global__ void stage_twiddle_build_kernel(Fe omega, uint32_t shift, uint32_t count, Fu* out) {
@@ -412,7 +423,7 @@ void ntt_twiddles_free(Ctx* c) {
         (void)hipFree(t.hi);
         if (t.stage[1] != t.stage[0]) (void)hipFree(t.stage[1]);
         (void)hipFree(t.stage[0]);
-        (void)hipFree(t.full);
+        for (int k = 0; k < 4; k++) (void)hipFree(t.full[k]);
     }
     c->twiddles.clear();
     c->tw_full_bytes = 0;
@@ -486,32 +497,37 @@ static int get_stage_twiddles(Ctx* c, const Fe& omega, uint32_t log_n, uint32_t 
     return 0;
 }
 
-// The two-pass plan's inter-pass twiddles omega^(k * lo) as a table of 2^log_n entries (38 MB at 2^20, 75 MB at 2^21), built once per domain
-// while the budget lasts: it replaces the multiplication that combines the two-level table, one of a pass's seven per element,
-// by a 36-byte coalesced read.  `p` carries the two-level table and s = the first pass's radix.  Leaves t->full null when the
-// budget is spent: the kernel then falls back to tw_pow.
-static int get_full_twiddles(Ctx* c, const Fe& omega, const NttPass& p, hipStream_t s, TwiddleTable* out) {
+// A pass's inter-pass twiddles as one table, built once per domain while the budget lasts: it replaces the multiplication that
+// combines the two-level table -- one of a pass's six or seven per element -- by a 36-byte read.  Slot 0: the two-pass plan's pass 1
+// (2^log_n entries [lo][k]: 38 MB at 2^20, 75 MB at 2^21).  Slots 1..3: strided pass t of the other plan (2^log_m entries [k][lo]).
+// `p` carries the two-level table, log_m and s.  Leaves the slot null when the budget is spent: the kernels fall back to tw_pow.
+static int get_full_twiddles(Ctx* c, const Fe& omega, const NttPass& p, int slot, hipStream_t s, TwiddleTable* out) {
     TwiddleKey key;
     for (int i = 0; i < 8; i++) key.omega[i] = omega.l[i];
     key.log_n = p.log_n;
     auto it = c->twiddles.find(key);
     if (it == c->twiddles.end()) return 0;
     TwiddleTable& t = it->second;
-    const size_t bytes = sizeof(Fu) << p.log_n;
-    if (t.full && t.full_s != p.s) {  // the plan changed under a tuning hook
+    const size_t bytes = sizeof(Fu) << p.log_m;
+    const uint32_t tag = (p.log_m << 8) | p.s;
+    if (t.full[slot] && t.full_tag[slot] != tag) {  // the plan changed under a tuning hook
         H2_CHECK(hipDeviceSynchronize());
-        (void)hipFree(t.full);
-        t.full = nullptr;
-        c->tw_full_bytes -= bytes;
+        (void)hipFree(t.full[slot]);
+        t.full[slot] = nullptr;
+        c->tw_full_bytes -= sizeof(Fu) << (t.full_tag[slot] >> 8);
     }
-    if (!t.full && c->tw_full_bytes + bytes <= g_ntt_full_budget) {
+    if (!t.full[slot] && c->tw_full_bytes + bytes <= g_ntt_full_budget) {
         Fu* d = nullptr;
         if (hipMalloc((void**)&d, bytes) == hipSuccess) {
-            hipLaunchKernelGGL(full_twiddle_build_kernel, dim3((uint32_t)(((uint64_t)1 << p.log_n) / 256)), dim3(256), 0, s, p, d);
+            const dim3 grid((uint32_t)((((uint64_t)1 << p.log_m) + 255) / 256));
+            if (slot == 0)
+                hipLaunchKernelGGL(full_twiddle_build_kernel, grid, dim3(256), 0, s, p, d);
+            else
+                hipLaunchKernelGGL(pass_twiddle_build_kernel, grid, dim3(256), 0, s, p, d);
             H2_CHECK(hipGetLastError());
             H2_CHECK(hipStreamSynchronize(s));
-            t.full = d;
-            t.full_s = p.s;
+            t.full[slot] = d;
+            t.full_tag[slot] = tag;
             c->tw_full_bytes += bytes;
         } else {
             (void)hipGetLastError();  // no room: not an error, the two-level table still serves
@@ -674,14 +690,14 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
         p.s = S[0];
         // up to 2^21 points the table (36 B per point), the data and the workspace share the 256 MB Infinity Cache: -6 %; at 2^22 they
         // no longer do and the table costs 7 % instead
-        if (log_n <= 21 && (rc = get_full_twiddles(c, omega, p, s, &tw))) return rc;
         p.log_m = log_n;
+        if (log_n <= 21 && (rc = get_full_twiddles(c, omega, p, 0, s, &tw))) return rc;
         p.log_j = 1;  // two columns (64-byte rows): four halve the workgroups and measure 6 % slower at 2^22, 24 % at 2^20
         for (int t = 0; t < 2; t++) {
             p.s = S[t];
             p.first = (t == 0);
             p.stage_tw = tw.stage[t];
-            p.tw_full = t == 0 ? tw.full : nullptr;
+            p.tw_full = t == 0 && g_ntt_full_budget ? tw.full[0] : nullptr;  // a zero budget also sets existing tables aside
             bind(t == 0 ? FIRST : WS, t == 0 ? WS : DATA);
             const dim3 grid(1u << (log_n - p.s - p.log_j), (uint32_t)count), block(1u << (p.s - 2));
             const size_t lds = sizeof(Fu) << p.s;
@@ -702,6 +718,7 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
         p.first = (t == 0);
         bool final = (t == P - 1);
         if (final) {
+            p.tw_full = nullptr;
             bind(P == 1 ? FIRST : WS, DATA);
             uint32_t log_nb = log_n - p.s;
             const uint32_t want_j = p.s <= 8 ? 2 : 1;  // 4 columns (128 B rows) up to 256-point tiles, 2 beyond: LDS
@@ -712,6 +729,12 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
             // the last strided pass goes out of place so the final pass lands in the data buffer; passes own
             // disjoint tiles, so reading elsewhere than they write is safe
             bind(t == 0 ? FIRST : DATA, t == P - 2 ? WS : DATA);
+            // a table of up to 2^20 entries (38 MB) stays cache-resident next to the data: every strided pass but the first of a large transform
+            p.tw_full = nullptr;
+            if (log_m <= 20 && t < 3) {
+                if ((rc = get_full_twiddles(c, omega, p, 1 + t, s, &tw))) return rc;
+                p.tw_full = g_ntt_full_budget ? tw.full[1 + t] : nullptr;
+            }
             uint32_t log_l = log_m - p.s;
             const uint32_t want_j = p.s <= 8 ? 2 : 1;
             p.log_j = log_l < want_j ? log_l : want_j;

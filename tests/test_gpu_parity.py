@@ -213,7 +213,8 @@ def test_ntt_full_size_2p22_roundtrip_and_oracle(h2, oracle):
 @pytest.mark.parametrize("k", [18, 19, 20, 21, 22])
 def test_ntt_two_pass_plan_equals_three_pass(h2, oracle, k):
     """The two plans of ntt.hip (two passes of 2^9..2^11-point tiles, three of 2^6..2^8) give the same limbs for the plain
-    transform, the scaled inverse and the zero-padded coset transform; the tuning hook forces each plan at every size."""
+    transform, the scaled inverse and the zero-padded coset transform, with the inter-pass twiddles read from their per-domain table
+    or combined from the two-level one; the tuning hooks force each at every size."""
     import ctypes
     import torch
     L = h2.lib()
@@ -222,8 +223,9 @@ def test_ntt_two_pass_plan_equals_three_pass(h2, oracle, k):
     a = h2.gen_scalars_device(77 + k, 1 << k)
     out = {}
     try:
-        for plan, (lo, hi) in (("three", (1, 0)), ("two", (18, 22))):
+        for plan, (lo, hi, budget) in (("three", (1, 0, 1 << 30)), ("two", (18, 22, 1 << 30)), ("three, two-level twiddles", (1, 0, 0)), ("two, two-level twiddles", (18, 22, 0))):
             L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(lo), ctypes.c_uint32(hi))
+            L.h2hip_debug_set_ntt_twiddle_budget(ctypes.c_uint64(budget))  # 0: inter-pass twiddles from the two-level table (one multiplication more)
             f = a.clone()
             h2.ntt_device(f, d.fe("extended_omega"), k)
             i = a.clone()
@@ -236,8 +238,10 @@ def test_ntt_two_pass_plan_equals_three_pass(h2, oracle, k):
             out[plan] = (f, i, e, b)
     finally:
         L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(20), ctypes.c_uint32(22))
-    for x, y in zip(out["two"], out["three"]):
-        assert torch.equal(x, y)
+        L.h2hip_debug_set_ntt_twiddle_budget(ctypes.c_uint64(1 << 30))
+    for plan, res in out.items():
+        for x, y in zip(res, out["three"]):
+            assert torch.equal(x, y), plan
 
 
 @pytest.mark.parametrize("k", [6])

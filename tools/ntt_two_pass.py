@@ -22,7 +22,7 @@ for k in [int(v) for v in os.environ.get("KS", "18,19,20,21,22").split(",")]:
     d = h2.EvaluationDomain.new(2, k)
     da = h2.gen_scalars_device(3, 1 << k)
     out = {}
-    for name, (lo, hi, budget) in (("three", (1, 0, 0)), ("two", (18, 22, 0)), ("two+table", (18, 22, 1 << 30))):
+    for name, (lo, hi, budget) in (("three", (1, 0, 0)), ("two", (18, 22, 0)), ("three+table", (1, 0, 1 << 30)), ("two+table", (18, 22, 1 << 30))):
         lib.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(lo), ctypes.c_uint32(hi))
         lib.h2hip_debug_set_ntt_twiddle_budget(ctypes.c_uint64(budget))
         x = da.clone(); h2.ntt_device(x, d.omega, k)
