@@ -26,7 +26,7 @@ void msm_set_quad_tail(bool on);
 void msm_set_split_buckets(bool on);
 void ecfft_set_quad(bool on);
 void msm_set_fuse_limits(size_t entries, size_t max_n);
-void msm_set_rowcol(uint64_t lanes, bool use_asm);
+void msm_set_rowcol(uint64_t lanes, uint32_t flavour);
 void ntt_set_smax(uint32_t v);
 void ntt_set_two_pass(uint32_t lo, uint32_t hi);
 void ntt_set_full_twiddle_budget(uint64_t bytes);
@@ -1667,7 +1667,7 @@ int h2hip_debug_set_msm_fuse_limits(size_t entries, size_t max_n) {
 
 // tuning hook: lane budget of the first row/column pass (default 65536 = one wave per SIMD) and its multiplier flavour
 int h2hip_debug_set_msm_rowcol(uint64_t lanes, int use_asm) {
-    msm_set_rowcol(lanes, use_asm != 0);
+    msm_set_rowcol(lanes, (uint32_t)use_asm);
     return 0;
 }
 

@@ -29,7 +29,8 @@
 //      msm_heavy_*             workgroup-per-chunk accumulation + LDS tree for over-full buckets
 //   C  msm_rowcol_kernel       summation by parts (arithmetic.rs:95-99) restated as plain sums: with the bucket
 //                              index b = hi * 2^s + lo,  sum (b+1) B_b = 2^s sum hi R_hi + sum (lo+1) C_lo  for the
-//                              row sums R and column sums C; applied twice, then
+//                              row sums R and column sums C; applied twice (first pass: msm_rowcol_qtree_kernel,
+//                              lane chains then a tree of quad-cooperative additions), then
 //      msm_final_kernel        <= 256 small multiples + one tree per bucket set
 //   D  host                    plain form only: Horner over the W set sums with c doublings each
 #include <hip/hip_ext.h>
@@ -579,6 +580,59 @@ __global__ void __launch_bounds__(256) msm_rowcol_kernel(RowColArgs args) {
     if (live && g == 0) J.out[task] = sh[threadIdx.x];
 }
 
+// The same sums for the first pass over a single bucket set (the fixed-base form's 2^19..2^21 buckets), where the work is
+// throughput -- 2 general additions per bucket -- and the lane kernel above loses a third of it to five tree levels on mostly
+// idle lanes at one wave per SIMD: here every lane chains only a few terms (four waves per SIMD reach the issue rate a lone wave
+// cannot), and the 2^g_log partials of a sum are then added pairwise by QUADS of lanes (ecq.cuh: a third of a lane's latency per
+// addition), 64 quads per workgroup, level by level through LDS.
+template <class F>
+__global__ void __launch_bounds__(256) msm_rowcol_qtree_kernel(RowColArgs args) {
+    __shared__ XYZZu sh[256];
+    uint32_t ji = 0;
+    for (uint32_t q = 1; q < args.n_jobs; q++)
+        if (blockIdx.x >= args.job[q].first_block) ji = q;
+    const RowColJob& J = args.job[ji];
+    const uint32_t G = 1u << J.g_log, g = threadIdx.x & (G - 1);
+    const uint32_t rows = 1u << J.log_rows, cols = 1u << J.log_cols;
+    const uint32_t per_arr = J.cols_kind ? cols : rows;
+    const uint32_t task = (blockIdx.x - J.first_block) * (256u >> J.g_log) + (threadIdx.x >> J.g_log);
+    const bool live = task < J.n_arr * per_arr;
+    XYZZu acc = xyzzu_identity();
+    if (live) {
+        const uint32_t a = task / per_arr, idx = task - a * per_arr;
+        const XYZZu* X = J.in + ((size_t)a << (J.log_rows + J.log_cols));
+        const XYZZu* first = J.cols_kind ? X + idx + ((size_t)g << J.log_cols) : X + ((size_t)idx << J.log_cols) + g;
+        const size_t step = J.cols_kind ? ((size_t)G << J.log_cols) : (size_t)G;
+        const uint32_t terms = J.cols_kind ? rows : cols;
+        if (g < terms) {
+            XYZZu cur = first[0];
+            for (uint32_t i = g + G; i < terms; i += G) {
+                first += step;
+                const XYZZu nxt = first[0];
+                xyzzu_add<F>(acc, cur);
+                cur = nxt;
+            }
+            xyzzu_add<F>(acc, cur);
+        }
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    const uint32_t quad = threadIdx.x >> 2, role = threadIdx.x & 3;
+    for (uint32_t stride = G >> 1; stride >= 1; stride >>= 1) {
+        // this level adds slot i + stride into slot i for the first `stride` slots of every sum: (256 / G) * stride additions
+        const uint32_t log_st = 31 - __clz(stride);
+        const uint32_t n_adds = (256u >> J.g_log) << log_st;
+        for (uint32_t a = quad; a < n_adds; a += 64) {
+            const uint32_t i = ((a >> log_st) << J.g_log) + (a & (stride - 1));
+            XYZZu x = sh[i];
+            xyzzu_add_q(x, sh[i + stride], role);
+            if (role == 0) sh[i] = x;
+        }
+        __syncthreads();
+    }
+    if (live && g == 0) J.out[task] = sh[threadIdx.x];
+}
+
 struct FinalArr {
     const XYZZu* base;  // array of set 0
     uint32_t stride;    // elements between consecutive sets
@@ -729,8 +783,12 @@ static uint32_t g_window_override = 0;
 static size_t g_heavy_div = 32768;
 static size_t g_bin_entries = 8192;
 static uint64_t g_rowcol_lanes = 65536;
-static bool g_rowcol_asm = false;
-void msm_set_rowcol(uint64_t lanes, bool use_asm) { g_rowcol_lanes = lanes ? lanes : 65536; g_rowcol_asm = use_asm; }
+static bool g_rowcol_asm = true, g_rowcol_qtree = true;  // first pass: chains on the explicit-mad multiplier, then the quad tree
+void msm_set_rowcol(uint64_t lanes, uint32_t flavour) {
+    g_rowcol_lanes = lanes ? lanes : 65536;
+    g_rowcol_asm = flavour & 1;
+    g_rowcol_qtree = flavour & 2;
+}
 static bool g_split_buckets = true;
 void msm_set_split_buckets(bool on) { g_split_buckets = on; }
 static bool g_quad_tail = true;
@@ -1037,12 +1095,15 @@ static int msm_stage_b(Ctx* c, const MsmLayout& L, char* base, const Affine* d_p
 
 // the two jobs (row sums, column sums) of one row/column pass over n_arr arrays of 2^log_rows x 2^log_cols elements.
 // Lanes per sum: every lane gets the same number of terms t, with t the smallest power of two that keeps the pass
-// within one wave per SIMD (a lone wave already saturates its SIMD's issue rate, so a second one only queues).
+// within the lane budget below.
 static void rowcol_jobs(RowColArgs* ra, const XYZZu* in, XYZZu* out_rows, XYZZu* out_cols, uint32_t n_arr, uint32_t log_rows, uint32_t log_cols,
                         uint32_t* n_blocks, bool quad = false) {
     const uint64_t elems = (uint64_t)n_arr << (log_rows + log_cols);
+    // one wave per SIMD while that keeps the chains at 16 terms (a second wave only shares the SIMD: measured 0.273 against 0.276 ms
+    // for a 2^20-pair MSM), two once they would grow longer (2^21 buckets: 0.66 against 0.70 ms)
+    const uint64_t budget = (2 * elems) >> 4 > g_rowcol_lanes ? 2 * g_rowcol_lanes : g_rowcol_lanes;
     uint32_t t_log = 1;
-    while (!quad && (2 * elems) >> t_log > g_rowcol_lanes) t_log++;
+    while (!quad && (2 * elems) >> t_log > budget) t_log++;
     for (uint32_t kind = 0; kind < 2; kind++) {
         RowColJob* j = &ra->job[ra->n_jobs++];
         const uint32_t log_terms = kind ? log_rows : log_cols, log_sums = kind ? log_cols : log_rows;
@@ -1092,7 +1153,9 @@ static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_sums, hip
         memset(&ra, 0, sizeof(ra));
         uint32_t nblk = 0;
         rowcol_jobs(&ra, buckets, RA, CA, ns, L.rb, L.s, &nblk);
-        if (g_rowcol_asm)
+        if (g_rowcol_qtree)
+            hipLaunchKernelGGL(msm_rowcol_qtree_kernel<FqUA>, dim3(nblk), dim3(256), 0, s, ra);
+        else if (g_rowcol_asm)
             hipLaunchKernelGGL(msm_rowcol_kernel<FqUA>, dim3(nblk), dim3(256), 0, s, ra);
         else
             hipLaunchKernelGGL(msm_rowcol_kernel<FqU>, dim3(nblk), dim3(256), 0, s, ra);
