@@ -179,6 +179,7 @@ __global__ void __launch_bounds__(256) k(Fu* a, int iters) {
         if (V == 3) x = fu_mul4<FqU>(x, y);
         if (V == 4) x = fu_mul5<FqU>(x, y);
         if (V == 5) x = fu_mul6<FqU>(x, y);
+        if (V == 6) x = fu_mul<FqUA>(x, y);  // the library's explicit-mad flavour: one asm statement per column and operand kind
     }
     a[i] = x;
 }
@@ -209,6 +210,9 @@ int main() {
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     int cus = prop.multiProcessorCount;
     Fu* d; hipMalloc(&d, (size_t)cus * 8 * 256 * sizeof(Fu) + 64); hipMemset(d, 1, (size_t)cus * 8 * 256 * sizeof(Fu) + 64);
-    for (int w : {1, 4, 8}) { run<0>(d, w, cus); run<3>(d, w, cus); run<5>(d, w, cus); }
+    // measured: lone wave 468 ns (variant 0), 669 (3: an s_nop after every asm statement), 467 (6); 8 waves per SIMD 167 / 177 / 183 G multiplies/s.
+    // Alternating two accumulators inside the column statements (tried, not kept) is slower everywhere: a lone wave is bound by issue
+    // (4.8 cycles per instruction), not by the accumulator dependency.
+    for (int w : {1, 2, 4, 8}) { run<0>(d, w, cus); run<3>(d, w, cus); run<6>(d, w, cus); }
     return 0;
 }
