@@ -186,6 +186,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # The contract is ONE JSON line on stdout.  Libraries underneath write to file descriptor 1 on their own (gloo announces its
+    # ranks there): from here on descriptor 1 is stderr, and rank 0 writes its line to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
@@ -552,7 +557,8 @@ def main():
             "next_rows": next_rows,
             "in_library_multi_gpu": inlib,
         }
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
