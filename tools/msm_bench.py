@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--quad-tail", type=int, default=1)
     ap.add_argument("--split", type=int, default=1)
     ap.add_argument("--rowcol-lanes", type=int, default=0)
-    ap.add_argument("--rowcol-asm", type=int, default=0)
+    ap.add_argument("--rowcol-asm", type=int, default=3, help="first row/column pass: bit 0 explicit-mad multiplier, bit 1 quad tree (3 = library default)")
     ap.add_argument("--skew", action="store_true", help="prover-like scalars: 90 %% zero, 5 %% in {1, 2}, 5 %% uniform")
     args = ap.parse_args()
     h2 = load_pkg()
