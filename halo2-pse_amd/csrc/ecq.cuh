@@ -30,14 +30,26 @@ __device__ __forceinline__ Fu quad_lane_fu(const Fu& x) {
     return o;
 }
 
-__device__ __forceinline__ Fu pick_fu(uint32_t role, const Fu& a0, const Fu& a1, const Fu& a2, const Fu& a3) {
+// Lane r of a quad takes a_r.  Written as explicit v_cndmask on three lane masks: LLVM turns the equivalent compare-and-select chain
+// into a scratch array indexed by the role (36 stores and 9 indexed loads per pick, in the middle of a latency chain).
+struct QuadMasks {
+    uint64_t m1, m2, m3;  // lanes with role 1, 2, 3
+};
+__device__ __forceinline__ QuadMasks quad_masks(uint32_t role) {
+    QuadMasks q;
+    q.m1 = __ballot(role == 1);
+    q.m2 = __ballot(role == 2);
+    q.m3 = __ballot(role == 3);
+    return q;
+}
+__device__ __forceinline__ Fu pick_fu(const QuadMasks& q, const Fu& a0, const Fu& a1, const Fu& a2, const Fu& a3) {
     Fu o;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-        int32_t v = a0.l[i];
-        v = role == 1 ? a1.l[i] : v;
-        v = role == 2 ? a2.l[i] : v;
-        v = role == 3 ? a3.l[i] : v;
+        int32_t v;
+        asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(v) : "v"(a0.l[i]), "v"(a1.l[i]), "s"(q.m1));
+        asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(a2.l[i]), "s"(q.m2));
+        asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(v) : "v"(a3.l[i]), "s"(q.m3));
         o.l[i] = v;
     }
     return o;
@@ -47,7 +59,8 @@ __device__ __forceinline__ Fu pick_fu(uint32_t role, const Fu& a0, const Fu& a1,
 template <int N>
 __device__ __forceinline__ void quad_products(uint32_t role, const Fu& a0, const Fu& b0, const Fu& a1, const Fu& b1, const Fu& a2, const Fu& b2,
                                               const Fu& a3, const Fu& b3, Fu& r0, Fu& r1, Fu& r2, Fu& r3) {
-    const Fu m = fu_mul<FqU>(pick_fu(role, a0, a1, a2, a3), pick_fu(role, b0, b1, b2, b3));
+    const QuadMasks q = quad_masks(role);
+    const Fu m = fu_mul<FqU>(pick_fu(q, a0, a1, a2, a3), pick_fu(q, b0, b1, b2, b3));
     r0 = quad_lane_fu<0>(m);
     if (N > 1) r1 = quad_lane_fu<1>(m);
     if (N > 2) r2 = quad_lane_fu<2>(m);

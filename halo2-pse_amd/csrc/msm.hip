@@ -624,8 +624,7 @@ __global__ void __launch_bounds__(256) msm_rowcol_qtree_kernel(RowColArgs args) 
         const uint32_t n_adds = (256u >> J.g_log) << log_st;
         for (uint32_t a = quad; a < n_adds; a += 64) {
             const uint32_t i = ((a >> log_st) << J.g_log) + (a & (stride - 1));
-            XYZZu x = sh[i];
-            xyzzu_add_q(x, sh[i + stride], role);
+            const XYZZu x = xyzzu_sum_q(sh[i], sh[i + stride], role);  // operands straight from LDS: a local copy of either went to scratch
             if (role == 0) sh[i] = x;
         }
         __syncthreads();
