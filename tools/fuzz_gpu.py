@@ -1,0 +1,59 @@
+"""Randomised cross-checks on the GPU box (not part of the test suite; run by hand):
+  * MSM: random sizes (not powers of two) and scalar shapes, plain form, fixed-base form and the CPU oracle agree in affine;
+  * NTT: every size 2^1..2^22, both plans and both twiddle sources agree limb for limb, round trips restore the input."""
+import ctypes, os, random, sys
+sys.path.insert(0, "/root/repo")
+import numpy as np
+from __graft_entry__ import load_pkg
+h2 = load_pkg(); h2.init(0)
+import torch
+from oracle import oracle
+NT = min(16, os.cpu_count() or 1)
+L = h2.lib()
+rng = random.Random(int(os.environ.get("SEED", "7")))
+
+bad = 0
+for it in range(int(os.environ.get("MSM_CASES", "24"))):
+    n = rng.choice([1, 2, 3, 63, 64, 65, 1000, 4097, rng.randrange(1, 70000), rng.randrange(1, 300000)])
+    bs = oracle.gen_points(1000 + it, n, num_threads=NT)
+    kind = rng.randrange(4)
+    sc = oracle.gen_scalars(2000 + it, n, num_threads=NT)
+    if kind == 1:
+        sc[rng.randrange(n):] = 0                                  # a zero tail
+    elif kind == 2:
+        m = np.array([rng.random() < 0.9 for _ in range(n)])
+        sc[m] = 0                                                  # prover-like: mostly zero
+        sc[~m, 1:] = 0; sc[~m, 0] &= np.uint64(3)                  # small values in Montgomery limbs are still big integers: fine, just skewed
+    elif kind == 3:
+        sc[:] = sc[0]                                              # one scalar everywhere: every point lands in the same bucket per window
+    want = oracle.g1_to_affine(oracle.best_multiexp(sc, bs, NT))
+    got_plain = h2.g1_to_affine(h2.best_multiexp(sc, bs))
+    h2.bases_pin(bs)
+    try:
+        got_fixed = h2.g1_to_affine(h2.best_multiexp(sc, bs))
+    finally:
+        h2.bases_unpin(bs)
+    ok = np.array_equal(got_plain, want) and np.array_equal(got_fixed, want)
+    bad += not ok
+    print("msm n=%d kind=%d %s" % (n, kind, "ok" if ok else "MISMATCH"), flush=True)
+
+for k in range(1, 23):
+    d = h2.EvaluationDomain.new(2, k)
+    a = h2.gen_scalars_device(40 + k, 1 << k)
+    outs = []
+    for lo, hi, budget in ((1, 0, 1 << 30), (18, 22, 1 << 30), (1, 0, 0), (18, 22, 0)):
+        L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(lo), ctypes.c_uint32(hi))
+        L.h2hip_debug_set_ntt_twiddle_budget(ctypes.c_uint64(budget))
+        x = a.clone(); h2.ntt_device(x, d.omega, k)
+        y = x.clone(); h2.ifft_device(y, d.omega_inv, k, d.ifft_divisor)
+        torch.cuda.synchronize()
+        outs.append((x, torch.equal(y, a)))
+    L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(20), ctypes.c_uint32(22))
+    L.h2hip_debug_set_ntt_twiddle_budget(ctypes.c_uint64(1 << 30))
+    ok = all(torch.equal(o[0], outs[0][0]) and o[1] for o in outs)
+    if k <= 16:
+        ok = ok and np.array_equal(h2.to_numpy_u64(outs[0][0]), oracle.best_fft(h2.to_numpy_u64(a).copy(), d.omega, k, NT))
+    bad += not ok
+    print("ntt 2^%d %s" % (k, "ok" if ok else "MISMATCH"), flush=True)
+print("FAILURES", bad)
+sys.exit(1 if bad else 0)
