@@ -11,6 +11,7 @@
 #include <thread>
 
 #include "../../include/halo2hip.h"
+#include "../../include/halo2hip_debug.h"
 #include "engine.h"
 
 namespace h2 {
@@ -19,6 +20,7 @@ int gen_scalars_device(uint64_t seed, uint64_t start, size_t n, Fe* d_out, hipSt
 int gen_points_device(uint64_t seed, uint64_t start, size_t n, Affine* d_out, hipStream_t s);
 void msm_set_window(uint32_t c);
 void msm_set_max_chunk(size_t m);
+void msm_set_stream(uint32_t chunks, double ratio, size_t min_n);
 void msm_set_heavy_div(size_t d);
 void msm_set_bin_entries(size_t d);
 void msm_set_bucket_order(int local);
@@ -625,6 +627,7 @@ static void make_zeta_scale(NttScale* sc, bool into_coset, const uint64_t g_cose
 
 
 static void release_ctx(Ctx* c) {
+    copier_stop(c);
     if (c->device >= 0) (void)hipSetDevice(c->device);
     if (c->ready) (void)hipDeviceSynchronize();
     c->timers_collect();
@@ -799,7 +802,7 @@ static int msm_shard_host(Ctx* c, const uint64_t* const* scalars, const uint64_t
     std::vector<const Fe*> sc(count);
     for (size_t j = 0; j < count; j++) sc[j] = (const Fe*)scalars[j] + lo;
     MsmTable tab;
-    const Affine* d_bases = nullptr;
+    const Affine *d_bases = nullptr, *h_bases = nullptr;
     const MsmTable* t = nullptr;
     auto it = c->pinned.find((const void*)bases_xy);
     if (it != c->pinned.end() && it->second.lo <= lo && lo + n <= it->second.hi) {
@@ -813,12 +816,9 @@ static int msm_shard_host(Ctx* c, const uint64_t* const* scalars, const uint64_t
             t = &tab;
         }
     } else {
-        int rc = c->msm_bases.ensure(n * sizeof(Affine));
-        if (rc) return rc;
-        H2_CHECK(hipMemcpyAsync(c->msm_bases.p, (const Affine*)bases_xy + lo, n * sizeof(Affine), hipMemcpyHostToDevice, c->stream));
-        d_bases = (const Affine*)c->msm_bases.p;
+        h_bases = (const Affine*)bases_xy + lo;  // unpinned: the points cross PCIe inside the run, chunk by chunk when it streams
     }
-    return msm_batch_device(c, sc.data(), true, d_bases, n, count, out, c->stream, t);
+    return msm_batch_device(c, sc.data(), true, d_bases, n, count, out, c->stream, t, h_bases);
 }
 
 // The partials of the devices meet: RCCL all-gather of 96 B per (device, MSM) as bytes when the engine holds
@@ -1644,6 +1644,13 @@ uint32_t h2hip_get_msm_window_fixed_base(size_t n) { return msm_table_window(n);
 // test hook: split inputs above m pairs into consecutive chunks (default 2^26, the 31-bit pair-index limit)
 int h2hip_debug_set_msm_max_chunk(size_t m) {
     msm_set_max_chunk(m);
+    return 0;
+}
+
+// test / tuning hook: a host-resident MSM of at least min_n pairs streams in `chunks` pieces whose sizes grow by 1 / ratio
+// (ratio_permille / 1000 = upload time over compute time per pair); chunks = 1 turns streaming off; zeros restore the defaults
+int h2hip_debug_set_msm_stream(uint32_t chunks, uint32_t ratio_permille, size_t min_n) {
+    msm_set_stream(chunks, ratio_permille / 1000.0, min_n);
     return 0;
 }
 

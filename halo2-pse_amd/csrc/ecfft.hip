@@ -257,6 +257,7 @@ int g_to_lagrange_device(Ctx* c, const Affine* d_g, uint32_t k, Affine* d_out, h
     int rc = c->ecfft_ws.ensure(xyzz_bytes + tw_bytes + 256);
     if (rc) return rc;
     if ((rc = c->ws_acquire(s))) return rc;
+    WsGuard guard(c, s);
     XYZZ* d_xyzz = (XYZZ*)c->ecfft_ws.p;
     GlvScalar* d_tw = (GlvScalar*)((char*)c->ecfft_ws.p + ((xyzz_bytes + 255) / 256) * 256);
     int tid = c->timer_begin("g_to_lagrange", s);
@@ -287,7 +288,7 @@ int g_to_lagrange_device(Ctx* c, const Affine* d_g, uint32_t k, Affine* d_out, h
     H2_CHECK(hipGetLastError());
     if ((rc = normalize_launch(d_xyzz, d_out, n, s))) return rc;
     c->timer_end(tid, s);
-    return c->ws_release(s);
+    return guard.release();
 }
 
 }  // namespace h2

@@ -93,6 +93,8 @@ struct StageTimer {
     bool pending = false;
 };
 
+struct Copier;  // msm.hip: helper thread that issues the host-to-device copies of a streamed MSM
+
 struct Ctx {
     int device = -1;
     bool ready = false;
@@ -130,6 +132,31 @@ struct Ctx {
     uint32_t aux_reserved = 0xffffffffu;  // CU reservation the aux streams were created with
     std::vector<hipEvent_t> aux_events;
     int ensure_aux(size_t n_events);
+    Copier* copier = nullptr;  // created on first use, joined by copier_stop (release_ctx)
+};
+
+void copier_stop(Ctx* c);
+
+// Between ws_acquire and ws_release a call owns the shared workspaces.  An error return in between must not leave kernels
+// queued on the internal streams unaccounted for: the guard drains them and still records the release, so the next
+// call (on whatever stream) waits for everything this one started.
+struct WsGuard {
+    Ctx* c;
+    hipStream_t s;
+    bool done = false;
+    WsGuard(Ctx* c_, hipStream_t s_) : c(c_), s(s_) {}
+    int release() {
+        done = true;
+        return c->ws_release(s);
+    }
+    ~WsGuard() {
+        if (done) return;
+        if (c->aux1) (void)hipStreamSynchronize(c->aux1);
+        if (c->aux2) (void)hipStreamSynchronize(c->aux2);
+        if (c->aux_b) (void)hipStreamSynchronize(c->aux_b);
+        (void)hipStreamSynchronize(s);
+        (void)c->ws_release(s);
+    }
 };
 
 Ctx* ctx();             // the primary device's context (device_ids[0] of h2hip_init)
@@ -174,7 +201,7 @@ void msm_set_fuse_small(bool on);
 // tab != nullptr: fixed-base form over tab's window table (d_bases unused)
 int msm_device(Ctx* c, const Fe* d_scalars, const Affine* d_bases, size_t n, XYZZ* h_out, hipStream_t s, const MsmTable* tab = nullptr);
 int msm_batch_device(Ctx* c, const Fe* const* scalars, bool scalars_on_host, const Affine* d_bases, size_t n, size_t count, XYZZ* h_out,
-                     hipStream_t s, const MsmTable* tab = nullptr);
+                     hipStream_t s, const MsmTable* tab = nullptr, const Affine* h_bases = nullptr);
 uint32_t msm_table_window(size_t n);  // window width a table for n pinned points is built with
 int msm_table_build(Ctx* c, const Affine* d_points, size_t n, uint32_t cw, Affine* d_table, hipStream_t s);
 

@@ -717,6 +717,7 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
     if (slots_ws && (rc = c->evalh_slots.ensure(slots_ws))) return rc;
     Fu* const gws = (Fu*)c->evalh_slots.p;
     if ((rc = c->ws_acquire(s))) return rc;
+    WsGuard guard(c, s);
     Arena ar;
     ar.base = (char*)c->evalh_ws.p;
     ar.cap = c->evalh_ws.cap;
@@ -886,7 +887,7 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         }
         H2_CHECK(hipGetLastError());
     }
-    if ((rc = c->ws_release(s))) return rc;
+    if ((rc = guard.release())) return rc;
     if (dev) return 0;
     H2_CHECK(hipMemcpyAsync(values, d_values, col_bytes, hipMemcpyDeviceToHost, s));
     H2_CHECK(hipStreamSynchronize(s));

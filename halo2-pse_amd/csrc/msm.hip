@@ -36,6 +36,9 @@
 #include <hip/hip_ext.h>
 #include <string.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <thread>
 #include <vector>
 
 #include "ecq.cuh"
@@ -396,7 +399,7 @@ __device__ __forceinline__ void accum_signed(XYZZu& acc, const Affine* __restric
 __global__ void __launch_bounds__(256) msm_accum_kernel(const Affine* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                         const uint32_t* __restrict__ start, const uint32_t* __restrict__ counts,
                                                         const uint32_t* __restrict__ perm, uint32_t n_buckets, uint32_t split_log, uint32_t heavy_t,
-                                                        uint32_t chunk, XYZZu* __restrict__ parts, uint32_t* __restrict__ heavy_counts,
+                                                        uint32_t chunk, uint32_t cont, XYZZu* __restrict__ parts, uint32_t* __restrict__ heavy_counts,
                                                         HeavyBucket* __restrict__ heavy_buckets, HeavyChunk* __restrict__ heavy_chunks) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if ((t >> split_log) >= n_buckets) return;
@@ -404,6 +407,8 @@ __global__ void __launch_bounds__(256) msm_accum_kernel(const Affine* __restrict
     const uint32_t b = perm[t >> split_log];  // buckets in descending size order
     uint32_t s = start[b], e = s + counts[b];
     XYZZu acc = xyzzu_identity();
+    XYZZu* const mine = parts + (((size_t)b << split_log) + sub);
+    bool store = !cont;  // cont: the parts hold the sums of the earlier chunks of a streamed MSM; a lane with nothing to add leaves its part alone
     if (e - s > heavy_t) {
         if (sub == 0) {
             uint32_t nch = (e - s + chunk - 1) / chunk;
@@ -447,6 +452,8 @@ __global__ void __launch_bounds__(256) msm_accum_kernel(const Affine* __restrict
         };
         uint32_t v = vals[s + sub];
         issue(v);
+        if (cont) acc = *mine;
+        store = true;
         for (uint32_t i = s + sub + S; i < e; i += S) {
             const uint32_t vn = vals[i];
             const Affine p = take();
@@ -457,10 +464,10 @@ __global__ void __launch_bounds__(256) msm_accum_kernel(const Affine* __restrict
         const Affine p = take();
         xyzzu_add_affine<FqUA>(acc, p, (v >> 31) != 0);
     }
-    parts[((size_t)b << split_log) + sub] = acc;
+    if (store) *mine = acc;
 }
 
-// B': bucket = sum of its 2^split_log parts (over-full buckets get the identity here and their sum from msm_heavy_final)
+// B': bucket = sum of its 2^split_log parts (msm_heavy_final has added an over-full bucket's sum to its first part by then)
 __global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZu* __restrict__ parts, uint32_t n_buckets, uint32_t split_log,
                                                           XYZZu* __restrict__ buckets) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -502,9 +509,10 @@ __global__ void __launch_bounds__(256) msm_heavy_chunk_kernel(const Affine* __re
     }
 }
 
-// B-heavy 2: one workgroup per over-full bucket sums its chunk sums into the bucket
+// B-heavy 2: one workgroup per over-full bucket adds its chunk sums to the bucket's first part (the accumulate kernel left the
+// bucket's parts alone: identities in a fresh run, the sums of the earlier chunks in a streamed one)
 __global__ void __launch_bounds__(256) msm_heavy_final_kernel(const uint32_t* __restrict__ heavy_counts, const HeavyBucket* __restrict__ heavy_buckets,
-                                                              const XYZZu* __restrict__ chunk_sums, XYZZu* __restrict__ buckets) {
+                                                              const XYZZu* __restrict__ chunk_sums, uint32_t split_log, XYZZu* __restrict__ parts) {
     __shared__ XYZZu sh[256];
     const uint32_t total = heavy_counts[0];
     for (uint32_t hi = blockIdx.x; hi < total; hi += gridDim.x) {
@@ -512,7 +520,12 @@ __global__ void __launch_bounds__(256) msm_heavy_final_kernel(const uint32_t* __
         XYZZu acc = xyzzu_identity();
         for (uint32_t q = threadIdx.x; q < h.n_chunks; q += blockDim.x) xyzzu_add(acc, chunk_sums[h.first_chunk + q]);
         XYZZu r = block_tree_sum(acc, sh);
-        if (threadIdx.x == 0) buckets[h.bucket] = r;
+        if (threadIdx.x == 0) {
+            XYZZu* dst = parts + ((size_t)h.bucket << split_log);
+            XYZZu cur = *dst;
+            xyzzu_add(cur, r);
+            *dst = cur;
+        }
         __syncthreads();
     }
 }
@@ -847,9 +860,9 @@ uint32_t msm_table_window(size_t n) {
     return normalise_window(c);
 }
 
-static MsmPlan make_plan(size_t n, bool fused, const MsmTable* tab) {
+static MsmPlan make_plan(size_t n, bool fused, const MsmTable* tab, uint32_t force_c = 0) {
     MsmPlan p;
-    uint32_t c = tab ? tab->c : plain_window(n, fused);
+    uint32_t c = tab ? tab->c : force_c ? force_c : plain_window(n, fused);
     if (c < 2) c = 2;
     if (c > 24) c = 24;
     p.W = (255 + c - 1) / c;
@@ -911,8 +924,12 @@ struct MsmLayout {
         o_RC, o_CR, o_CC, o_sums, o_partials, o_hb, o_hc, o_hs, o_ptrs, total;
 };
 
-static int msm_layout(size_t n, MsmLayout* L, uint32_t fuse, const MsmTable* tab) {
-    MsmPlan p = make_plan(n, fuse > 1, tab);
+// force_c / force_split: the chunks of a streamed MSM (msm_stream_host) all use the window width and the lanes-per-bucket
+// split of the whole MSM, so that they add into the same parts; -1 / 0 = derive them from n.
+// The regions whose size depends only on the plan (buckets, parts, reduction arrays) come first: every chunk layout of a
+// streamed MSM has them at the same offsets, and stages B and C take their base address separately (`bbase`).
+static int msm_layout(size_t n, MsmLayout* L, uint32_t fuse, const MsmTable* tab, uint32_t force_c = 0, int force_split = -1) {
+    MsmPlan p = make_plan(n, fuse > 1, tab, force_c);
     L->p = p;
     L->n = n;
     L->fuse = fuse;
@@ -956,6 +973,7 @@ static int msm_layout(size_t n, MsmLayout* L, uint32_t fuse, const MsmTable* tab
     L->split_log = 0;
     while (L->split_log < 3 && ((uint64_t)L->K << (L->split_log + 1)) <= (1u << 18) && (mean_bucket >> (L->split_log + 1)) >= 2) L->split_log++;
     if (!g_split_buckets) L->split_log = 0;
+    if (force_split >= 0) L->split_log = (uint32_t)force_split;
     L->max_chunks = L->E / p.chunk + L->E / p.heavy_t + 16;  // sum of ceil(cnt/chunk) over buckets with cnt > heavy_t
     L->max_heavy = L->E / p.heavy_t + 16;
     // reduction geometry
@@ -969,6 +987,7 @@ static int msm_layout(size_t n, MsmLayout* L, uint32_t fuse, const MsmTable* tab
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t E = L->E;
     const uint32_t K = L->K, ns = L->n_sets;
+    // -- plan-sized regions (offsets independent of n)
     L->o_zero = off;  // one memset clears: coarse counts, coarse cursors, heavy counters
     L->o_ccnt = carve((size_t)MSM_MAX_C1 * 4);
     L->o_ccur = carve((size_t)MSM_MAX_C1 * 4);
@@ -976,8 +995,6 @@ static int msm_layout(size_t n, MsmLayout* L, uint32_t fuse, const MsmTable* tab
     L->o_hcnt = carve(16);
     L->o_zero_end = off;
     L->o_cstart = carve(((size_t)MSM_MAX_C1 + 1) * 4);
-    L->o_tmp = carve(E * 8);
-    L->o_vals = carve(E * 4);
     L->o_start = carve((size_t)K * 4);
     L->o_counts = carve((size_t)K * 4);
     L->o_perm = carve((size_t)K * 4);
@@ -991,10 +1008,13 @@ static int msm_layout(size_t n, MsmLayout* L, uint32_t fuse, const MsmTable* tab
     L->o_CC = carve(((size_t)ns << L->s3) * sizeof(XYZZu));
     L->o_sums = carve((size_t)ns * sizeof(XYZZ));
     L->o_partials = carve((size_t)ns * 16 * sizeof(XYZZu));
+    L->o_ptrs = carve((size_t)fuse * sizeof(void*));
+    // -- regions sized by the entries of the run
+    L->o_tmp = carve(E * 8);
+    L->o_vals = carve(E * 4);
     L->o_hb = carve(L->max_heavy * sizeof(HeavyBucket));
     L->o_hc = carve(L->max_chunks * sizeof(HeavyChunk));
     L->o_hs = carve(L->max_chunks * sizeof(XYZZu));
-    L->o_ptrs = carve((size_t)fuse * sizeof(void*));
     L->total = off;
     return 0;
 }
@@ -1055,40 +1075,45 @@ static int msm_stage_a(Ctx* c, const MsmLayout& L, char* base, const Fe* const* 
     return 0;
 }
 
-// stage B (VALU-bound): bucket accumulation, plus the chunked path for over-full buckets
-static int msm_stage_b(Ctx* c, const MsmLayout& L, char* base, const Affine* d_points, hipStream_t s) {
+// stage B (VALU-bound): bucket accumulation, plus the chunked path for over-full buckets.  `base` holds the sorted entries of
+// this run, `bbase` the parts / buckets they are added to (the same arena unless the run is one chunk of a streamed MSM);
+// cont: the parts already hold sums (msm_accum_kernel); combine: fold the parts of every bucket afterwards.
+static int msm_stage_b(Ctx* c, const MsmLayout& L, char* base, const Affine* d_points, hipStream_t s, char* bbase = nullptr, bool cont = false,
+                       bool combine = true) {
     const MsmPlan& p = L.p;
+    if (!bbase) bbase = base;
     uint32_t* vals = (uint32_t*)(base + L.o_vals);
     uint32_t *start = (uint32_t*)(base + L.o_start), *counts = (uint32_t*)(base + L.o_counts), *perm = (uint32_t*)(base + L.o_perm);
-    XYZZu* buckets = (XYZZu*)(base + L.o_buckets);
+    XYZZu* buckets = (XYZZu*)(bbase + L.o_buckets);
     uint32_t* hcnt = (uint32_t*)(base + L.o_hcnt);
     HeavyBucket* hb = (HeavyBucket*)(base + L.o_hb);
     HeavyChunk* hc = (HeavyChunk*)(base + L.o_hc);
     XYZZu* hs = (XYZZu*)(base + L.o_hs);
     int t2 = c->timer_begin("msm_accum", s);
     hipEvent_t ke0 = nullptr, ke1 = nullptr;
-    XYZZu* parts = (XYZZu*)(base + L.o_parts);
+    XYZZu* parts = (XYZZu*)(bbase + L.o_parts);
     const uint32_t lanes = L.K << L.split_log;
+    const uint32_t cont_u = cont ? 1u : 0u;
     if (c->timer_kernel("msm_accum", &ke0, &ke1) >= 0)  // the dispatch's own begin / end timestamps: no marker packets around it
         hipExtLaunchKernelGGL(msm_accum_kernel, dim3((lanes + g_accum_bs - 1) / g_accum_bs), dim3(g_accum_bs), 0, s, ke0, ke1, 0, d_points, vals, start,
-                              counts, perm, L.K, L.split_log, p.heavy_t, p.chunk, parts, hcnt, hb, hc);
+                              counts, perm, L.K, L.split_log, p.heavy_t, p.chunk, cont_u, parts, hcnt, hb, hc);
     else
         hipLaunchKernelGGL(msm_accum_kernel, dim3((lanes + g_accum_bs - 1) / g_accum_bs), dim3(g_accum_bs), 0, s, d_points, vals, start, counts, perm,
-                           L.K, L.split_log, p.heavy_t, p.chunk, parts, hcnt, hb, hc);
+                           L.K, L.split_log, p.heavy_t, p.chunk, cont_u, parts, hcnt, hb, hc);
     H2_CHECK(hipGetLastError());
-    if (L.split_log) {
-        hipLaunchKernelGGL(msm_combine_kernel, dim3((L.K + 255) / 256), dim3(256), 0, s, (const XYZZu*)parts, L.K, L.split_log, buckets);
-        H2_CHECK(hipGetLastError());
-    }
     c->timer_end(t2, s);
     int t3 = c->timer_begin("msm_heavy", s);
     uint32_t hgrid = (uint32_t)(L.max_chunks < (size_t)c->sm_count * 4 ? L.max_chunks : (size_t)c->sm_count * 4);
     hipLaunchKernelGGL(msm_heavy_chunk_kernel, dim3(hgrid), dim3(256), 0, s, d_points, vals, hcnt, hc, hs);
     H2_CHECK(hipGetLastError());
     uint32_t fgrid = (uint32_t)(L.max_heavy < (size_t)c->sm_count ? L.max_heavy : (size_t)c->sm_count);
-    hipLaunchKernelGGL(msm_heavy_final_kernel, dim3(fgrid), dim3(256), 0, s, hcnt, hb, hs, buckets);
+    hipLaunchKernelGGL(msm_heavy_final_kernel, dim3(fgrid), dim3(256), 0, s, hcnt, hb, hs, L.split_log, parts);
     H2_CHECK(hipGetLastError());
     c->timer_end(t3, s);
+    if (L.split_log && combine) {
+        hipLaunchKernelGGL(msm_combine_kernel, dim3((L.K + 255) / 256), dim3(256), 0, s, (const XYZZu*)parts, L.K, L.split_log, buckets);
+        H2_CHECK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -1240,6 +1265,7 @@ static int msm_batch_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_h
     XYZZ* h_ws = (XYZZ*)c->host_ws.p;
     rc = c->ws_acquire(s);
     if (rc) return rc;
+    WsGuard guard(c, s);
     int t_all = c->timer_begin("msm_total", s);
     if (count == 1) {
         char* base = (char*)c->msm_slot[0].p;
@@ -1279,7 +1305,7 @@ static int msm_batch_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_h
     c->timer_end(t_all, s);
     H2_CHECK(hipStreamSynchronize(s));
     for (size_t j = 0; j < count; j++) h_out[j] = finish_msm(h_ws + j * spm, L.p);
-    return c->ws_release(s);
+    return guard.release();
 }
 
 // Small MSMs over the same bases, fused: the `count` MSMs run as ONE pass of the three stages whose bucket sets are
@@ -1294,6 +1320,7 @@ static int msm_fused_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_h
     if ((rc = c->msm_slot[0].ensure(L.total))) return rc;
     std::vector<const Fe*> list(d_scalars, d_scalars + count);
     if ((rc = c->ws_acquire(s))) return rc;
+    WsGuard guard(c, s);
     if (scalars_on_host) {
         if ((rc = c->msm_scalars[0].ensure(count * n * sizeof(Fe)))) return rc;
         for (size_t j = 0; j < count; j++) {
@@ -1313,7 +1340,304 @@ static int msm_fused_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_h
     H2_CHECK(hipStreamSynchronize(s));
     const uint32_t spm = sets_per_msm(L.p);
     for (size_t j = 0; j < count; j++) h_out[j] = finish_msm(h_ws + j * spm, L.p);
-    return c->ws_release(s);
+    return guard.release();
+}
+
+// ---- host-resident scalars: the upload runs under the work -------------------------------------------------------------------
+// best_multiexp hands over host slices (arithmetic.rs:132; one call per column at plonk/prover.rs:361-365), 32 B per pair over
+// PCIe (~0.55 ms per 2^20 pairs).  A lone MSM is cut into K chunks of growing size; chunk k + 1 crosses PCIe (copy stream) and is
+// sorted (sort stream) while chunk k is accumulated, and every chunk adds into the SAME parts / buckets (msm_accum_kernel with
+// cont = 1), so the bucket reduction is paid once.  Chunk sizes form the geometric ladder f_k ~ r^-k with r = (upload time) /
+// (compute time) per pair: each upload then ends as the previous chunk's work does, and only the first -- the smallest --
+// upload is exposed.  What streaming costs: a bucket's first addition of a chunk is a full mixed addition (into a fresh bucket
+// it is two multiplications), ~7 multiplications per bucket and extra chunk, hence few chunks.
+// The copies are hipMemcpyAsync from the caller's (pageable) memory in chunk-sized pieces: HIP pins the pages and the DMA runs at
+// PCIe speed, the call returns when its piece has left -- by which time the previous chunk's kernels are queued and running.
+// swept on MI355X (tools/stream_sweep.py; 2^20 / 2^22 / 2^24 pairs, pinned bases): 3 chunks at ratio 0.6 -- 1.62 / 5.36 / 19.4 ms
+// against 1.87 / 7.35 / 27.8 ms with the whole upload first and 1.27 / 4.60 / 17.0 ms device-resident.  With the bases crossing
+// too (unpinned, 96 B per pair) the run is upload-bound: more and nearly equal chunks (6 at 3 x 0.4), 2.55 / 8.3 / 31.3 ms
+// against 3.44 / 13.2 / 51.2 ms.
+static uint32_t g_stream_chunks = 3;
+static double g_stream_ratio = 0.6;
+static size_t g_stream_min_n = (size_t)1 << 19;  // 2^19 pairs: 1.13 -> 1.04 ms (two chunks); 2^18: 0.72 -> 0.80 ms, not worth it
+void msm_set_stream(uint32_t chunks, double ratio, size_t min_n) {
+    g_stream_chunks = chunks ? chunks : 3;
+    g_stream_ratio = ratio > 0 ? ratio : 0.6;
+    g_stream_min_n = min_n ? min_n : ((size_t)1 << 19);
+}
+
+// The copies are issued by a helper thread (one per device context): hipMemcpyAsync from pageable memory returns only when
+// its piece has left the host, and the thread that enqueues the kernels must not sit in it -- with one thread doing both, chunk
+// k + 1 started to cross PCIe only after chunk k's launches were queued and the sort of chunk k + 1 only a launch latency after
+// its copy had ended: no overlap was left (measured, rocprofv3 timeline of round 3).  The copier walks a job list; after each
+// job it records the job's event (if any) on its copy stream and bumps `done`; the enqueueing thread spins on `done` -- a
+// chunk is at most a few hundred microseconds away -- and then makes its stream wait on the event.
+struct CopyJob {
+    void* dst;
+    const void* src;
+    size_t bytes;
+    hipEvent_t ev;  // recorded on the copy stream after this job; nullptr: none
+};
+
+struct Copier {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<CopyJob> jobs;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    bool has_work = false, quit = false;
+    std::atomic<size_t> done{0};
+    std::atomic<int> err{0};
+};
+
+static void copier_main(Copier* cp) {
+    (void)hipSetDevice(cp->device);
+    std::unique_lock<std::mutex> lk(cp->m);
+    for (;;) {
+        cp->cv.wait(lk, [&] { return cp->has_work || cp->quit; });
+        if (cp->quit) return;
+        cp->has_work = false;
+        std::vector<CopyJob> jobs;
+        jobs.swap(cp->jobs);
+        hipStream_t st = cp->stream;
+        lk.unlock();
+        for (size_t i = 0; i < jobs.size(); i++) {
+            if (!cp->err.load(std::memory_order_relaxed)) {
+                hipError_t e = hipMemcpyAsync(jobs[i].dst, jobs[i].src, jobs[i].bytes, hipMemcpyHostToDevice, st);
+                if (e == hipSuccess && jobs[i].ev) e = hipEventRecord(jobs[i].ev, st);
+                if (e != hipSuccess) cp->err.store((int)e);
+            }
+            cp->done.fetch_add(1, std::memory_order_release);
+        }
+        lk.lock();
+    }
+}
+
+// hand `jobs` to c's copier (started on first use); the caller then follows `done` with copier_wait
+static int copier_submit(Ctx* c, std::vector<CopyJob>& jobs, hipStream_t stream) {
+    if (!c->copier) {
+        c->copier = new Copier();
+        c->copier->device = c->device;
+        c->copier->th = std::thread(copier_main, c->copier);
+    }
+    Copier* cp = c->copier;
+    std::lock_guard<std::mutex> lk(cp->m);
+    cp->jobs.swap(jobs);
+    cp->stream = stream;
+    cp->done.store(0);
+    cp->err.store(0);
+    cp->has_work = true;
+    cp->cv.notify_all();
+    return 0;
+}
+
+// block until the first n_jobs jobs of the current list have been issued (for pageable sources: have left the host)
+static int copier_wait(Ctx* c, size_t n_jobs) {
+    Copier* cp = c->copier;
+    uint32_t spins = 0;
+    while (cp->done.load(std::memory_order_acquire) < n_jobs)
+        if (++spins > 2000) std::this_thread::yield();
+    if (int e = cp->err.load()) {
+        set_error("msm: host-to-device copy of a streamed chunk failed: %s", hipGetErrorString((hipError_t)e));
+        return 2;
+    }
+    return 0;
+}
+
+void copier_stop(Ctx* c) {
+    Copier* cp = c->copier;
+    if (!cp) return;
+    {
+        std::lock_guard<std::mutex> lk(cp->m);
+        cp->quit = true;
+        cp->cv.notify_all();
+    }
+    cp->th.join();
+    delete cp;
+    c->copier = nullptr;
+}
+
+// a streamed run owns the copier until every job has been issued: an early error return must not leave it reading the caller's
+// arrays (or this frame's events) behind the call's back
+struct CopierDrain {
+    Ctx* c;
+    size_t n_jobs;
+    ~CopierDrain() {
+        Copier* cp = c->copier;
+        if (!cp || cp->done.load(std::memory_order_acquire) >= n_jobs) return;
+        if (!cp->err.load()) cp->err.store((int)hipErrorUnknown);  // the jobs not yet started are skipped
+        while (cp->done.load(std::memory_order_acquire) < n_jobs) std::this_thread::yield();
+    }
+};
+
+// units cut into at most K pieces with sizes ~ r^-k, each a multiple of `quantum` (the last takes the remainder)
+static void stream_ladder(size_t units, uint32_t K, double r, size_t quantum, std::vector<size_t>* out) {
+    out->clear();
+    if (K < 1) K = 1;
+    while (K > 1 && units < (size_t)K * quantum * 2) K--;
+    std::vector<double> f(K);
+    double w = 1.0, tot = 0.0;
+    for (uint32_t k = 0; k < K; k++) {
+        f[k] = w;
+        tot += w;
+        w /= r;
+    }
+    size_t used = 0;
+    for (uint32_t k = 0; k + 1 < K; k++) {
+        size_t m = (size_t)((double)units * f[k] / tot / (double)quantum + 0.5) * quantum;
+        if (m < quantum) m = quantum;
+        if (used + m + quantum > units) break;
+        out->push_back(m);
+        used += m;
+    }
+    out->push_back(units - used);
+}
+
+static int msm_stream_host(Ctx* c, const Fe* h_scalars, const Affine* h_bases, const Affine* d_points, const MsmTable* tab, size_t n, XYZZ* h_out,
+                           hipStream_t s) {
+    std::vector<size_t> sz;
+    const uint32_t kk = n < ((size_t)1 << 20) && g_stream_chunks > 2 ? 2 : g_stream_chunks;
+    stream_ladder(n, h_bases ? 2 * kk : kk, h_bases ? 2.0 * g_stream_ratio : g_stream_ratio, 4096, &sz);
+    const size_t K = sz.size();
+    MsmLayout Lt;
+    int rc = msm_layout(n, &Lt, 1, tab);
+    if (rc) return rc;
+    std::vector<MsmLayout> Lk(K);
+    size_t need = 0;
+    for (size_t k = 0; k < K; k++) {
+        if ((rc = msm_layout(sz[k], &Lk[k], 1, tab, Lt.p.c, (int)Lt.split_log))) return rc;
+        if (Lk[k].total > need) need = Lk[k].total;
+    }
+    if ((rc = c->msm_slot[0].ensure(need))) return rc;
+    if ((rc = c->msm_scalars[0].ensure(n * sizeof(Fe)))) return rc;
+    Fe* d_sc = (Fe*)c->msm_scalars[0].p;
+    Affine* d_bs = nullptr;
+    if (h_bases) {
+        if ((rc = c->msm_bases.ensure(n * sizeof(Affine)))) return rc;
+        d_bs = (Affine*)c->msm_bases.p;
+        d_points = d_bs;
+    }
+    const uint32_t spm = sets_per_msm(Lt.p);
+    if ((rc = c->host_ws.ensure(spm * sizeof(XYZZ)))) return rc;
+    XYZZ* h_ws = (XYZZ*)c->host_ws.p;
+    if ((rc = c->ensure_aux(K + 2))) return rc;
+    if ((rc = c->ws_acquire(s))) return rc;
+    WsGuard guard(c, s);
+    int t_all = c->timer_begin("msm_total", s);
+    // Sort and accumulation of all chunks run in order on ONE stream.  Putting the sort of chunk k + 1 on a second stream under
+    // the accumulation of chunk k was slower: the accumulation holds every wave slot and 64 KB of LDS per CU, the sort's
+    // workgroups (1024 lanes, 136 KB) only got onto the chip in its tail, both kernels ran 10-30 % longer and the next
+    // accumulation still waited for the sort (timeline in profiles/r03_stream_*).
+    hipStream_t cs = c->aux2;
+    hipEvent_t* ev = c->aux_events.data();  // [0] start, [1 + k] chunk k uploaded
+    H2_CHECK(hipEventRecord(ev[0], s));
+    H2_CHECK(hipStreamWaitEvent(cs, ev[0], 0));
+    char* base = (char*)c->msm_slot[0].p;
+    const Affine* points0 = tab ? tab->table : d_points;
+    size_t o = 0;
+    std::vector<CopyJob> jobs;
+    for (size_t k = 0; k < K; k++) {
+        if (h_bases) jobs.push_back(CopyJob{d_bs + o, h_bases + o, sz[k] * sizeof(Affine), nullptr});
+        jobs.push_back(CopyJob{d_sc + o, h_scalars + o, sz[k] * sizeof(Fe), ev[1 + k]});
+        o += sz[k];
+    }
+    const size_t per_chunk = h_bases ? 2 : 1;
+    H2_CHECK(hipStreamSynchronize(s));  // the copies start now: whatever was queued ahead of this call has to be done with the buffers
+    if ((rc = copier_submit(c, jobs, cs))) return rc;
+    CopierDrain drain{c, K * per_chunk};
+    o = 0;
+    for (size_t k = 0; k < K; k++) {
+        if ((rc = copier_wait(c, (k + 1) * per_chunk))) return rc;
+        H2_CHECK(hipStreamWaitEvent(s, ev[1 + k], 0));
+        const Fe* sc = d_sc + o;
+        if ((rc = msm_stage_a(c, Lk[k], base, &sc, tab, s))) return rc;
+        if ((rc = msm_stage_b(c, Lk[k], base, points0 + o, s, base, k > 0, k + 1 == K))) return rc;
+        o += sz[k];
+    }
+    if ((rc = msm_stage_c(c, Lk[K - 1], base, h_ws, s))) return rc;
+    c->timer_end(t_all, s);
+    H2_CHECK(hipStreamSynchronize(s));
+    h_out[0] = finish_msm(h_ws, Lt.p);
+    return guard.release();
+}
+
+// The fused batch with host-resident columns: groups of columns (a ladder again), each group one fused run on its own stream and
+// workspace slot -- group g + 1 crosses PCIe while group g is sorted and accumulated, and its reduction tail (a latency chain on a
+// few waves) runs under the next group's accumulation.
+static int msm_fused_groups_host(Ctx* c, const Fe* const* h_scalars, const Affine* d_points, const MsmTable* tab, size_t n, size_t count,
+                                 size_t fuse_max, XYZZ* h_out, hipStream_t s) {
+    std::vector<size_t> ladder, groups;
+    stream_ladder(count, g_stream_chunks, g_stream_ratio * 0.85, 1, &ladder);  // 16 columns: 2 + 5 + 9
+    for (size_t g : ladder)
+        for (size_t o = 0; o < g; o += fuse_max) groups.push_back(g - o < fuse_max ? g - o : fuse_max);
+    const size_t G = groups.size();
+    std::vector<MsmLayout> Lg(G);
+    size_t need = 0, max_sets = 0;
+    int rc;
+    for (size_t g = 0; g < G; g++) {
+        if ((rc = msm_layout(n, &Lg[g], (uint32_t)groups[g], tab))) return rc;
+        if (Lg[g].total > need) need = Lg[g].total;
+        max_sets += Lg[g].n_sets;
+    }
+    for (int k = 0; k < 2; k++)
+        if ((rc = c->msm_slot[k].ensure(need))) return rc;
+    if ((rc = c->msm_scalars[0].ensure(count * n * sizeof(Fe)))) return rc;
+    if ((rc = c->host_ws.ensure(max_sets * sizeof(XYZZ)))) return rc;
+    XYZZ* h_ws = (XYZZ*)c->host_ws.p;
+    if ((rc = c->ensure_aux(3 * G + 2))) return rc;
+    if ((rc = c->ws_acquire(s))) return rc;
+    WsGuard guard(c, s);
+    int t_all = c->timer_begin("msm_total", s);
+    // sort + accumulate of every group in order on one stream (they would only fight for the same wave slots side by side), the
+    // reduction of group g -- a latency chain on a few waves -- on a second stream under group g + 1; two workspace slots
+    hipStream_t cs = c->aux2, sa = c->aux_b, sc_ = c->aux1;
+    hipEvent_t* ev = c->aux_events.data();  // [0] start, [1 + 3g] group g uploaded, [2 + 3g] accumulated, [3 + 3g] reduced
+    H2_CHECK(hipEventRecord(ev[0], s));
+    H2_CHECK(hipStreamWaitEvent(cs, ev[0], 0));
+    H2_CHECK(hipStreamWaitEvent(sa, ev[0], 0));
+    H2_CHECK(hipStreamWaitEvent(sc_, ev[0], 0));
+    std::vector<const Fe*> list(count);
+    size_t j0 = 0, set0 = 0;
+    std::vector<CopyJob> jobs;
+    for (size_t g = 0; g < G; g++) {
+        for (size_t j = j0; j < j0 + groups[g]; j++) {
+            Fe* dst = (Fe*)c->msm_scalars[0].p + j * n;
+            jobs.push_back(CopyJob{dst, h_scalars[j], n * sizeof(Fe), j + 1 == j0 + groups[g] ? ev[1 + 3 * g] : nullptr});
+            list[j] = dst;
+        }
+        j0 += groups[g];
+    }
+    H2_CHECK(hipStreamSynchronize(s));  // as in msm_stream_host
+    if ((rc = copier_submit(c, jobs, cs))) return rc;
+    CopierDrain drain{c, count};
+    j0 = 0;
+    for (size_t g = 0; g < G; g++) {
+        const size_t cnt = groups[g];
+        if ((rc = copier_wait(c, j0 + cnt))) return rc;
+        char* base = (char*)c->msm_slot[g & 1].p;
+        H2_CHECK(hipStreamWaitEvent(sa, ev[1 + 3 * g], 0));
+        if (g >= 2) H2_CHECK(hipStreamWaitEvent(sa, ev[3 + 3 * (g - 2)], 0));  // the slot is free once group g - 2 is reduced
+        if ((rc = msm_stage_a(c, Lg[g], base, list.data() + j0, tab, sa))) return rc;
+        if ((rc = msm_stage_b(c, Lg[g], base, d_points, sa))) return rc;
+        H2_CHECK(hipEventRecord(ev[2 + 3 * g], sa));
+        H2_CHECK(hipStreamWaitEvent(sc_, ev[2 + 3 * g], 0));
+        if ((rc = msm_stage_c(c, Lg[g], base, h_ws + set0, sc_))) return rc;
+        H2_CHECK(hipEventRecord(ev[3 + 3 * g], sc_));
+        j0 += cnt;
+        set0 += Lg[g].n_sets;
+    }
+    H2_CHECK(hipStreamWaitEvent(s, ev[3 + 3 * (G - 1)], 0));  // the reductions are in order on their stream
+    c->timer_end(t_all, s);
+    H2_CHECK(hipStreamSynchronize(s));
+    j0 = set0 = 0;
+    for (size_t g = 0; g < G; g++) {  // a group of one column has the lone MSM's window width, not the fused one
+        const uint32_t spm = sets_per_msm(Lg[g].p);
+        for (size_t j = 0; j < groups[g]; j++) h_out[j0 + j] = finish_msm(h_ws + set0 + j * spm, Lg[g].p);
+        j0 += groups[g];
+        set0 += Lg[g].n_sets;
+    }
+    return guard.release();
 }
 
 // measured (tools/fuse_big.py, 8 MSMs per batch, per MSM): 2^19 pairs fused 0.66 ms / pipelined 0.69 ms, 2^20 pairs fused 1.24 / pipelined 1.16
@@ -1322,16 +1646,18 @@ void msm_set_fuse_limits(size_t entries, size_t max_n) { g_fuse_entries = entrie
 static bool g_fuse_small = true;
 void msm_set_fuse_small(bool on) { g_fuse_small = on; }
 
-// count MSMs over the same bases for device-resident inputs; results (XYZZ) to host memory.  tab != nullptr: the
-// fixed-base form over tab's table (d_bases is then unused).
+// count MSMs over the same bases; results (XYZZ) to host memory.  tab != nullptr: the fixed-base form over tab's table
+// (d_bases is then unused).  scalars_on_host: scalars[j] are host pointers.  h_bases != nullptr: the bases are the
+// caller's host array and cross PCIe inside the call (d_bases unused).
 int msm_batch_device(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, const Affine* d_bases, size_t n, size_t count, XYZZ* h_out,
-                     hipStream_t s, const MsmTable* tab) {
+                     hipStream_t s, const MsmTable* tab, const Affine* h_bases) {
     for (size_t j = 0; j < count; j++) h_out[j] = xyzz_identity();
     if (n == 0 || count == 0) return 0;
     if (tab && n > tab->stride) {
         set_error("msm: %zu pairs exceed the %zu points of the fixed-base table", n, tab->stride);
         return 1;
     }
+    if (tab) h_bases = nullptr;
     // the entry index lives in 31 bits: split very large inputs
     const size_t max_chunk = g_max_chunk;
     std::vector<const Fe*> ptrs(count);
@@ -1348,6 +1674,20 @@ int msm_batch_device(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, c
             tsub = &sub;
             points = sub.table;
         }
+        const bool stream = scalars_on_host && g_stream_chunks > 1;
+        if (stream && count == 1 && m >= g_stream_min_n) {  // a lone host-resident MSM: chunks stream in under the work
+            int rc = msm_stream_host(c, ptrs[0], h_bases ? h_bases + o : nullptr, points, tsub, m, part.data(), s);
+            if (rc) return rc;
+            xyzz_add(h_out[0], part[0]);
+            continue;
+        }
+        if (h_bases) {  // whole upload ahead of the run
+            int rc = c->msm_bases.ensure(m * sizeof(Affine));
+            if (rc) return rc;
+            if ((rc = c->ws_acquire(s))) return rc;
+            H2_CHECK(hipMemcpyAsync(c->msm_bases.p, h_bases + o, m * sizeof(Affine), hipMemcpyHostToDevice, s));
+            points = (const Affine*)c->msm_bases.p;
+        }
         // up to 2^19 pairs each: fused runs of at most 2^26 entries, MSM_MAX_C1 << MSM_MAX_L buckets and MSM_MAX_C1
         // bucket sets; larger MSMs: pipelined over streams
         const MsmPlan fp = make_plan(m, true, tsub);
@@ -1358,11 +1698,16 @@ int msm_batch_device(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, c
         if (fuse_max > by_buckets) fuse_max = by_buckets;
         if (fuse_max > by_sets) fuse_max = by_sets;
         if (g_fuse_small && count > 1 && m <= g_fuse_max_n && fuse_max >= 2) {
-            for (size_t j0 = 0; j0 < count; j0 += fuse_max) {
-                const size_t g = count - j0 < fuse_max ? count - j0 : fuse_max;
-                int rc = g == 1 ? msm_batch_chunk(c, ptrs.data() + j0, scalars_on_host, points, tsub, m, 1, part.data() + j0, s)
-                                : msm_fused_chunk(c, ptrs.data() + j0, scalars_on_host, points, tsub, m, g, part.data() + j0, s);
+            if (stream && count * m >= g_stream_min_n) {
+                int rc = msm_fused_groups_host(c, ptrs.data(), points, tsub, m, count, fuse_max, part.data(), s);
                 if (rc) return rc;
+            } else {
+                for (size_t j0 = 0; j0 < count; j0 += fuse_max) {
+                    const size_t g = count - j0 < fuse_max ? count - j0 : fuse_max;
+                    int rc = g == 1 ? msm_batch_chunk(c, ptrs.data() + j0, scalars_on_host, points, tsub, m, 1, part.data() + j0, s)
+                                    : msm_fused_chunk(c, ptrs.data() + j0, scalars_on_host, points, tsub, m, g, part.data() + j0, s);
+                    if (rc) return rc;
+                }
             }
         } else {
             int rc = msm_batch_chunk(c, ptrs.data(), scalars_on_host, points, tsub, m, count, part.data(), s);
@@ -1375,7 +1720,7 @@ int msm_batch_device(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, c
 
 // Sum of coeffs[i]*bases[i] for device-resident inputs; result (XYZZ) to host memory.
 int msm_device(Ctx* c, const Fe* d_scalars, const Affine* d_bases, size_t n, XYZZ* h_out, hipStream_t s, const MsmTable* tab) {
-    return msm_batch_device(c, &d_scalars, false, d_bases, n, 1, h_out, s, tab);
+    return msm_batch_device(c, &d_scalars, false, d_bases, n, 1, h_out, s, tab, nullptr);
 }
 
 // Build the fixed-base table for n device-resident points: rows 0..W-1 of n points each, row j = 2^(pos_j) * P with pos_j the
@@ -1390,6 +1735,7 @@ int msm_table_build(Ctx* c, const Affine* d_points, size_t n, uint32_t cw, Affin
     int rc = c->ecfft_ws.ensure(m_max * sizeof(XYZZ));
     if (rc) return rc;
     if ((rc = c->ws_acquire(s))) return rc;
+    WsGuard guard(c, s);
     XYZZ* tmp = (XYZZ*)c->ecfft_ws.p;
     for (uint32_t j = 1; j < W; j++) {
         for (size_t o = 0; o < n; o += slice) {
@@ -1400,7 +1746,7 @@ int msm_table_build(Ctx* c, const Affine* d_points, size_t n, uint32_t cw, Affin
             if ((rc = ec_normalize_device(tmp, d_table + (size_t)j * n + o, m, s))) return rc;
         }
     }
-    return c->ws_release(s);
+    return guard.release();
 }
 
 }  // namespace h2

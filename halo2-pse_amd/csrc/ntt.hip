@@ -549,6 +549,7 @@ int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const uint64_t* h_t, uint
     }
     int rc = c->ws_acquire(s);
     if (rc) return rc;
+    WsGuard guard(c, s);
     rc = c->misc.ensure((size_t)t_len * sizeof(Fu));
     if (rc) return rc;
     std::vector<Fu> t(t_len);
@@ -563,7 +564,7 @@ int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const uint64_t* h_t, uint
     uint32_t grid = (uint32_t)(blocks < (uint64_t)c->sm_count * 16 ? blocks : (uint64_t)c->sm_count * 16);
     hipLaunchKernelGGL(scale_periodic_kernel, dim3(grid), dim3(256), 0, s, d_a, n, (const Fu*)c->misc.p, t_len);
     H2_CHECK(hipGetLastError());
-    return c->ws_release(s);
+    return guard.release();
 }
 
 static uint32_t g_ntt_smax = 8;
@@ -620,6 +621,7 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
     }
     int rc0 = c->ws_acquire(s);
     if (rc0) return rc0;
+    WsGuard guard(c, s);
     int tid = c->timer_begin("ntt", s);
     const bool two = log_n >= g_ntt_two_lo && log_n <= g_ntt_two_hi;
     uint32_t S[4];
@@ -671,7 +673,7 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
         hipLaunchKernelGGL(ntt_n1_kernel, dim3(1, (uint32_t)count), dim3(64), 0, s, p);
         H2_CHECK(hipGetLastError());
         c->timer_end(tid, s);
-        return c->ws_release(s);
+        return guard.release();
     }
     TwiddleTable tw;
     rc = get_twiddles(c, omega, log_n, s, &tw);
@@ -707,7 +709,7 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
             H2_CHECK(hipGetLastError());
         }
         c->timer_end(tid, s);
-        return c->ws_release(s);
+        return guard.release();
     }
     uint32_t log_m = log_n;
     for (int t = 0; t < P; t++) {
@@ -752,7 +754,7 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
         log_m -= p.s;
     }
     c->timer_end(tid, s);
-    return c->ws_release(s);
+    return guard.release();
 }
 
 int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttScale* sc, hipStream_t s, const Fe* d_src) {

@@ -84,6 +84,7 @@ int kzg_setup_device(Ctx* c, uint32_t k, const Fe& s, Affine* d_g, Affine* d_gl,
     const Fe mult = fe_mul<FrP>(fe_sub<FrP>(s_n, fe_one<FrP>()), n_inv);
     int rc = c->ws_acquire(stream);
     if (rc) return rc;
+    WsGuard guard(c, stream);
     // the generator's table: XYZZ from the host, normalised to affine on the device, kept for the life of the context
     const size_t tab_points = (size_t)SETUP_WIN * SETUP_DIG;
     if (!c->gen_table.p) {
@@ -112,7 +113,7 @@ int kzg_setup_device(Ctx* c, uint32_t k, const Fe& s, Affine* d_g, Affine* d_gl,
     H2_CHECK(hipGetLastError());
     if ((rc = ec_normalize_device(tmp, d_gl, n, stream))) return rc;  // :106-116
     c->timer_end(tid, stream);
-    return c->ws_release(stream);
+    return guard.release();
 }
 
 }  // namespace h2

@@ -308,42 +308,7 @@ int h2hip_profile_enable(int on);
 int h2hip_profile_reset(void);
 int h2hip_profile_get(const char* stage, double* total_ms, uint64_t* count);
 
-/* ---- test and tuning hooks (not part of the drop-in surface; used by tests/ and tools/ only) ---- */
-
-/* split MSM inputs above m pairs into consecutive chunks (default 2^26, the 31-bit pair-index limit; 0 restores it) */
-int h2hip_debug_set_msm_max_chunk(size_t m);
-/* push `count` Jacobian partials per engine device through the library's RCCL all-gather (communicators created on
- * demand, also for one device) and fold them on the host: exercises the multi-GPU gather on any box */
-int h2hip_debug_rccl_gather_selftest(const uint64_t* partials_xyz, size_t count, uint64_t* out_xyz);
-/* buckets with more than (entries of the MSM) / d entries take the chunked path (default d = 32768; 0 restores it) */
-int h2hip_debug_set_msm_heavy_div(size_t d);
-/* g_to_lagrange up to k = 14: one quad of lanes per butterfly (1, default) or one lane (0) */
-int h2hip_debug_set_g2l_quad(int on);
-/* fused batches: at most `entries` entries per fused run (0 = 2^26), MSMs of at most `max_n` pairs are fused (0 = 2^19) */
-int h2hip_debug_set_msm_fuse_limits(size_t entries, size_t max_n);
-/* first row/column pass of the reduction: lane budget (0 = 65536, one wave per SIMD) and explicit-mad multiplier (1) or plain (0) */
-int h2hip_debug_set_msm_rowcol(uint64_t lanes, int use_asm);
-/* accumulation of runs with fewer than 2^18 buckets: up to 8 lanes per bucket (1, default) or one (0) */
-int h2hip_debug_set_msm_split_buckets(int on);
-/* reduction tail: one quad of lanes per group operation (1, default) or one lane each (0) */
-int h2hip_debug_set_msm_quad_tail(int on);
-/* 1: accumulate order = buckets by size inside each sort bin only; 0 (default): global size order */
-int h2hip_debug_set_msm_bucket_order(int local);
-/* target entries per coarse bin of the MSM's two-level sort (default 8192; 0 restores it) */
-int h2hip_debug_set_msm_bin_entries(size_t d);
-/* CUs reserved for the sort / reduce streams of a batched MSM (0 = none: every split measured slower) */
-int h2hip_debug_set_reserved_cus(uint32_t k);
-/* batches of MSMs of up to 2^19 pairs: fused into one run (1, default) or pipelined over streams (0) */
-int h2hip_debug_set_msm_fuse_small(int on);
-/* largest log2 tile of an NTT pass (4..10; default 8, 9 beyond 2^24 points) */
-int h2hip_debug_set_ntt_smax(uint32_t v);
-int h2hip_debug_set_lazy_pin(uint32_t after);
-int h2hip_debug_set_ntt_two_pass(uint32_t lo, uint32_t hi);
-int h2hip_debug_set_ntt_twiddle_budget(uint64_t bytes);
-/* evaluate_h: programs needing more slots than v use the global-workspace form of the kernels (default 256) */
-int h2hip_debug_set_evalh_max_local_slots(uint32_t v);
-/* evaluate_h: compile a graph as the engine would and report the program's size; needs no GPU */
-int h2hip_debug_evalh_compile_stats(const h2hip_graph* g, uint32_t* n_ops, uint32_t* n_slots);
+/* Test and tuning hooks (h2hip_debug_*) are declared in halo2hip_debug.h; they are not part of the drop-in surface. */
 
 #ifdef __cplusplus
 }

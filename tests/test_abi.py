@@ -10,10 +10,18 @@ import pytest
 from conftest import ROOT
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "halo2hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(h2hip_[a-z0-9_]+)\s*\(", text)))
+def _declared_symbols(headers=("halo2hip.h", "halo2hip_debug.h")):
+    syms = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        syms |= set(re.findall(r"\b(h2hip_[a-z0-9_]+)\s*\(", text))
+    return sorted(syms)
+
+
+def test_debug_hooks_live_in_their_own_header():
+    assert not [s for s in _declared_symbols(("halo2hip.h",)) if s.startswith("h2hip_debug_")]
+    assert all(s.startswith("h2hip_debug_") for s in _declared_symbols(("halo2hip_debug.h",)))
 
 
 def test_header_declares_expected_entry_points():
