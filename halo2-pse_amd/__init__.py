@@ -179,13 +179,35 @@ def bases_unpin(bases):
     _check(lib().h2hip_bases_unpin(_p(bases)), "h2hip_bases_unpin")
 
 
+_device_pins = {}  # device address -> weakref.finalize of the tensor that was pinned
+
+
+def _unpin_address(addr):
+    _device_pins.pop(addr, None)
+    try:
+        lib().h2hip_bases_unpin(ctypes.c_void_p(addr))
+    except Exception:
+        pass
+
+
 def bases_pin_device(d_bases, n=None):
-    """pin device-resident points (torch CUDA tensor): copies them and builds the fixed-base window table"""
+    """pin device-resident points (torch CUDA tensor): copies them and builds the fixed-base window table.  The tensor's
+    address is the cache key, so the entry is tied to the tensor's lifetime: when the tensor is dropped without
+    bases_unpin_device the entry goes with it (the library's own fingerprint check is the second line of defence)."""
+    import weakref
     n = d_bases.numel() * d_bases.element_size() // 64 if n is None else int(n)
     _check(lib().h2hip_bases_pin_device(_dptr(d_bases), ctypes.c_size_t(n), _stream()), "h2hip_bases_pin_device")
+    addr = d_bases.data_ptr()
+    old = _device_pins.pop(addr, None)
+    if old is not None:
+        old.detach()
+    _device_pins[addr] = weakref.finalize(d_bases, _unpin_address, addr)
 
 
 def bases_unpin_device(d_bases):
+    fin = _device_pins.pop(d_bases.data_ptr(), None)
+    if fin is not None:
+        fin.detach()
     _check(lib().h2hip_bases_unpin(_dptr(d_bases)), "h2hip_bases_unpin")
 
 

@@ -8,11 +8,15 @@
 
 #include <condition_variable>
 #include <functional>
+#include <shared_mutex>
 #include <thread>
 
 #include "../../include/halo2hip.h"
 #include "../../include/halo2hip_debug.h"
 #include "engine.h"
+
+// the optional lazy pin cache (further down, outside the namespace)
+static void lazy_forget(const void* key);
 
 namespace h2 {
 
@@ -99,6 +103,13 @@ void DevBuf::release() {
 // One Ctx per device of h2hip_init's list.  g_ctx is the primary (device_ids[0]); its mutex serialises the entry
 // points.  The other devices only ever run MSM shards (best_multiexp splits its pairs the same way over rayon
 // threads, arithmetic.rs:137-153), each from its own worker thread.
+// Locking (round 3; one process-wide mutex before): g_engine_mu is held shared by every entry point and exclusively by
+// h2hip_init / h2hip_shutdown, so the device list cannot change under a running call.  Each device context has its own
+// mutex: a `_device` entry point locks only the context that owns its pointers, so calls on different GPUs -- and concurrent
+// best_fft callers spread over devices (plonk/permutation/keygen.rs:216-233) -- overlap.  Entry points that touch every
+// device (host-pointer MSMs over several GPUs, pin / unpin, pinned_info) lock all contexts in list order; the lazy-pin
+// bookkeeping and the configuration are only touched under the first context's mutex.
+static std::shared_mutex g_engine_mu;
 static Ctx g_ctx;
 static std::vector<Ctx*> g_devs;  // g_devs[0] == &g_ctx once ready
 Ctx* ctx() { return &g_ctx; }
@@ -246,7 +257,7 @@ struct Config {
     size_t multi_gpu_min_n = (size_t)1 << 18;  // HALO2_HIP_MULTI_GPU_MIN_N: smaller MSMs stay on the primary device
     size_t msm_min_n = (size_t)1 << 10;        // HALO2_HIP_MSM_MIN_N: below this the Rust shim keeps the CPU body
     uint32_t ntt_min_log_n = 10;               // HALO2_HIP_NTT_MIN_LOGN: likewise for best_fft
-    bool gather_rccl = true;                   // HALO2_HIP_GATHER=host|rccl: how the devices' partials meet
+    bool gather_rccl = false;                  // HALO2_HIP_GATHER=rccl: the devices' set sums meet through ncclAllGather (default: host fold)
     bool fixed_base = true;                    // HALO2_HIP_FIXED_BASE=0: h2hip_bases_pin keeps the points only
     size_t table_max_bytes = (size_t)160 << 30;  // HALO2_HIP_TABLE_MAX_GB: largest window table built at pin time
     bool allow_dup = false;                    // HALO2_HIP_ALLOW_DUPLICATE_DEVICES=1: rehearsal on a one-GPU box
@@ -279,7 +290,7 @@ static void read_config() {
     if (env_u64("HALO2_HIP_NTT_TWIDDLE_MB", &v)) ntt_set_full_twiddle_budget(v << 20);
     if (env_u64("HALO2_HIP_MSM_WINDOW", &v) && v >= 2 && v <= 24) msm_set_window((uint32_t)v);
     const char* g = getenv("HALO2_HIP_GATHER");
-    if (g && !strcmp(g, "host")) c.gather_rccl = false;
+    if (g && !strcmp(g, "rccl")) c.gather_rccl = true;
     g_cfg = c;
 }
 
@@ -424,8 +435,7 @@ static int on_devices(int n_use, const std::function<int(int)>& f) {
 }
 
 static bool unpin_everywhere(const void* key);
-static void pinned_validate(const uint64_t* bases_xy, size_t n);
-static const MsmTable* pinned_table(Ctx* c, const void* key, size_t n, const Affine** points, MsmTable* out);
+static bool pinned_validate(const uint64_t* bases_xy, size_t n);
 
 static int init_one(Ctx* c, int dev) {
     H2_CHECK(hipSetDevice(dev));
@@ -446,7 +456,7 @@ static void release_ctx(Ctx* c);
 
 static int do_init(const int* device_ids, int n_ids) {
     Ctx* c = ctx();
-    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    std::unique_lock<std::shared_mutex> lk(g_engine_mu);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
@@ -520,10 +530,11 @@ static int do_init(const int* device_ids, int n_ids) {
 }
 
 int ensure_init() {
-    Ctx* c = ctx();
-    std::lock_guard<std::recursive_mutex> lk(c->mu);
-    if (c->ready) return 0;
-    return do_init(nullptr, 0);
+    {
+        std::shared_lock<std::shared_mutex> lk(g_engine_mu);
+        if (ctx()->ready) return 0;
+    }
+    return do_init(nullptr, 0);  // takes the engine lock exclusively; a second thread arriving here finds the engine ready
 }
 
 static inline Fe fe_from_u64x4(const uint64_t v[4]) {
@@ -548,14 +559,20 @@ static int check_fr(const uint64_t v[4], const char* what) {
 
 struct Entry {
     Ctx* c;
-    std::unique_lock<std::recursive_mutex> lk;
+    std::shared_lock<std::shared_mutex> engine;
+    std::vector<std::unique_lock<std::recursive_mutex>> held;  // the contexts this call owns, in list order
     int rc;
     bool ranged = false;
-    // d_ptr: a device pointer of the call, or nullptr; with several devices the call runs on the device that owns it
-    explicit Entry(const char* name = nullptr, const void* d_ptr = nullptr) : c(ctx()), rc(0) {
-        rc = ensure_init();
-        if (rc) return;
-        lk = std::unique_lock<std::recursive_mutex>(c->mu);
+    // d_ptr: a device pointer of the call, or nullptr; with several devices the call runs on the device that owns it.
+    // all_devices: the call reads or changes every device's state (pinned caches, multi-device MSM).
+    explicit Entry(const char* name = nullptr, const void* d_ptr = nullptr, bool all_devices = false) : c(ctx()), rc(0) {
+        for (;;) {
+            rc = ensure_init();
+            if (rc) return;
+            engine = std::shared_lock<std::shared_mutex>(g_engine_mu);
+            if (ctx()->ready) break;
+            engine.unlock();  // shut down by another thread in between: initialise again
+        }
         if (d_ptr && g_devs.size() > 1) {
             hipPointerAttribute_t at;
             if (hipPointerGetAttributes(&at, d_ptr) == hipSuccess) {
@@ -574,6 +591,11 @@ struct Entry {
             } else {
                 (void)hipGetLastError();
             }
+        }
+        if (all_devices) {
+            for (Ctx* x : g_devs) held.emplace_back(x->mu);
+        } else {
+            held.emplace_back(c->mu);
         }
         if (hipSetDevice(c->device) != hipSuccess) {
             set_error("hipSetDevice(%d) failed", c->device);
@@ -633,8 +655,12 @@ static void release_ctx(Ctx* c) {
     c->timers_collect();
     c->timers.clear();
     ntt_twiddles_free(c);
-    for (auto& kv : c->pinned) (void)hipFree(kv.second.d);
+    for (auto& kv : c->pinned) {
+        (void)hipFree(kv.second.d);
+        if (kv.second.d_sample) (void)hipFree(kv.second.d_sample);
+    }
     c->pinned.clear();
+    c->pin_flag.release();
     c->ntt_ws.release();
     c->ntt_io.release();
     for (int k = 0; k < 3; k++) {
@@ -676,18 +702,21 @@ static bool unpin_everywhere(const void* key) {
         (void)hipSetDevice(x->device);
         (void)hipDeviceSynchronize();
         (void)hipFree(it->second.d);
+        if (it->second.d_sample) (void)hipFree(it->second.d_sample);
         x->pinned.erase(it);
     }
     if (!g_devs.empty()) (void)hipSetDevice(g_devs[0]->device);
     return found;
 }
 
-// a host-keyed pinned entry is valid for this call only if n fits and the caller's array still carries the sampled
-// points; anything else is a stale entry and is dropped
-static void pinned_validate(const uint64_t* bases_xy, size_t n) {
+// A host-keyed pinned entry serves this call only if n fits and the caller's array still carries the sampled points:
+// a mismatch means the allocation was freed and reused -- the entry is dropped on every device.  A prefix so short that
+// fewer than four samples fall inside it (n <= total >> 12) is not vouched for by the fingerprint (point 0 of every KZG
+// `g` is the generator): such a call bypasses the entry (returns false, entry kept) and uploads its few points.
+static bool pinned_validate(const uint64_t* bases_xy, size_t n) {
     Ctx* c = ctx();
     auto it = c->pinned.find((const void*)bases_xy);
-    if (it == c->pinned.end() || it->second.device_key) return;
+    if (it == c->pinned.end() || it->second.device_key) return true;
     size_t total = 0;
     for (Ctx* x : g_devs) {
         auto jt = x->pinned.find((const void*)bases_xy);
@@ -695,32 +724,82 @@ static void pinned_validate(const uint64_t* bases_xy, size_t n) {
     }
     bool ok = n <= total;
     if (ok) {
-        for (size_t k = 0; ok && k < H2_PIN_SAMPLES; k++) {
-            const size_t i = (size_t)((unsigned __int128)(total - 1) * k / (H2_PIN_SAMPLES - 1));
-            if (i < n || n == total) ok = memcmp(it->second.sample + 64 * k, bases_xy + 8 * i, 64) == 0;
+        for (uint32_t k = 0; ok && k < H2_PIN_SAMPLES; k++) {
+            const size_t i = pin_sample_index(total, k);
+            if (i < n) ok = memcmp(it->second.sample + 64 * k, bases_xy + 8 * i, 64) == 0;
         }
     }
-    if (!ok) (void)unpin_everywhere((const void*)bases_xy);
+    if (!ok) {
+        ::lazy_forget((const void*)bases_xy);
+        (void)unpin_everywhere((const void*)bases_xy);
+        return true;  // nothing left to bypass
+    }
+    return n == total || n > pin_sample_index(total, 3);
 }
 
-// window table of a device-pointer key on context c (h2hip_bases_pin_device), if n fits
-static const MsmTable* pinned_table(Ctx* c, const void* key, size_t n, const Affine** points, MsmTable* out) {
+// ---- device-pointer keys (h2hip_bases_pin_device) ---------------------------------------------------------------------------
+// The key is a device address; torch's caching allocator hands the same address out again readily, so a caller that freed a
+// pinned buffer without unpinning it would get the OLD table's commitments.  Guard: the entry keeps H2_PIN_SAMPLES points of
+// the array in device memory; a one-wave kernel queued ahead of the MSM compares them with the caller's buffer and writes its
+// verdict to a pinned host word, which is read when the MSM's own result has arrived (the call waits for that anyway: no extra
+// synchronisation).  A mismatch drops the entry and the MSM is run again in the plain form over the caller's points.
+__global__ void pin_sample_kernel(const Affine* __restrict__ src, size_t total, Affine* __restrict__ out) {
+    if (threadIdx.x < H2_PIN_SAMPLES) out[threadIdx.x] = src[pin_sample_index(total, threadIdx.x)];
+}
+
+__global__ void pin_check_kernel(const Affine* __restrict__ bases, size_t n, size_t total, const Affine* __restrict__ samples, uint32_t* flag) {
+    const uint32_t k = threadIdx.x >> 2, part = threadIdx.x & 3;  // 16 points x 4 pieces of 16 B
+    const size_t idx = pin_sample_index(total, k);
+    if (idx >= n) return;
+    const uint4 a = reinterpret_cast<const uint4*>(&bases[idx])[part], b = reinterpret_cast<const uint4*>(&samples[k])[part];
+    if (a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w) atomicOr(flag, 1u);
+}
+
+// window table of a device-pointer key on context c, if n fits; *entry gets the cache entry
+static const MsmTable* pinned_table(Ctx* c, const void* key, size_t n, MsmTable* out, const PinnedBases** entry) {
     auto it = c->pinned.find(key);
-    if (it == c->pinned.end() || !it->second.device_key || n > it->second.n) return nullptr;
-    if (points) *points = (const Affine*)it->second.d;
-    if (!it->second.c) return nullptr;
+    if (it == c->pinned.end() || !it->second.device_key || n > it->second.n || !it->second.c) return nullptr;
     out->table = (const Affine*)it->second.d;
     out->stride = it->second.n;
     out->c = it->second.c;
     out->W = it->second.W;
+    *entry = &it->second;
     return out;
+}
+
+// `count` MSMs over device-resident scalars and bases on context c: the fixed-base form when d_bases is a pinned key whose
+// fingerprint still matches, else the plain form.  Synchronous (the sums come back through the host).
+static int msm_device_keyed(Ctx* c, const Fe* const* d_scalars, const Affine* d_bases, size_t n, size_t count, XYZZ* out, hipStream_t s) {
+    MsmTable tab;
+    const PinnedBases* pb = nullptr;
+    const MsmTable* t = (n && count) ? pinned_table(c, d_bases, n, &tab, &pb) : nullptr;
+    if (t && n != pb->n && n <= pin_sample_index(pb->n, 3)) t = nullptr;  // too short a prefix for the fingerprint to vouch for: plain form
+    volatile uint32_t* flag = nullptr;
+    if (t && pb->d_sample) {
+        int rc = c->pin_flag.ensure(64);
+        if (rc) return rc;
+        flag = (volatile uint32_t*)c->pin_flag.p;
+        *flag = 0;
+        hipLaunchKernelGGL(pin_check_kernel, dim3(1), dim3(64), 0, s, d_bases, n, pb->n, (const Affine*)pb->d_sample, (uint32_t*)c->pin_flag.p);
+        H2_CHECK(hipGetLastError());
+    }
+    int rc = msm_batch_device(c, d_scalars, false, d_bases, n, count, out, s, t);
+    if (rc || !flag || !*flag) return rc;
+    // stale: another array lives at the pinned address now
+    H2_CHECK(hipDeviceSynchronize());
+    auto it = c->pinned.find((const void*)d_bases);
+    if (it != c->pinned.end()) {
+        (void)hipFree(it->second.d);
+        if (it->second.d_sample) (void)hipFree(it->second.d_sample);
+        c->pinned.erase(it);
+    }
+    return msm_batch_device(c, d_scalars, false, d_bases, n, count, out, s, nullptr);
 }
 
 }  // namespace h2
 
 using namespace h2;
 
-static void lazy_forget(const void* key);
 static void lazy_reset();
 static void lazy_pin_consider(const uint64_t* bases_xy, size_t n);
 
@@ -730,7 +809,7 @@ int h2hip_init(const int* device_ids, int n_devices) { return do_init(device_ids
 
 void h2hip_shutdown(void) {
     Ctx* c = ctx();
-    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    std::unique_lock<std::shared_mutex> lk(g_engine_mu);  // waits for every running entry point
     if (!c->ready) return;
     for (size_t i = 1; i < g_workers.size(); i++) {
         Worker* w = g_workers[i];
@@ -764,9 +843,8 @@ int h2hip_device_count(void) {
 }
 
 int h2hip_num_devices(void) {
-    Ctx* c = ctx();
-    std::lock_guard<std::recursive_mutex> lk(c->mu);
-    return c->ready ? (int)g_devs.size() : 0;
+    std::shared_lock<std::shared_mutex> lk(g_engine_mu);
+    return ctx()->ready ? (int)g_devs.size() : 0;
 }
 
 size_t h2hip_msm_min_n(void) {
@@ -788,9 +866,8 @@ int h2hip_msm_bn254_device(const void* d_scalars, const void* d_bases_xy, size_t
     if (en.rc) return en.rc;
     hipStream_t s = (hipStream_t)stream;
     XYZZ r;
-    MsmTable tab;
-    const MsmTable* t = n ? pinned_table(en.c, d_bases_xy, n, nullptr, &tab) : nullptr;
-    int rc = msm_device(en.c, (const Fe*)d_scalars, (const Affine*)d_bases_xy, n, &r, s, t);
+    const Fe* sc = (const Fe*)d_scalars;
+    int rc = msm_device_keyed(en.c, &sc, (const Affine*)d_bases_xy, n, 1, &r, s);
     if (rc) return rc;
     xyzz_to_out(r, out_xyz);
     return 0;
@@ -798,14 +875,15 @@ int h2hip_msm_bn254_device(const void* d_scalars, const void* d_bases_xy, size_t
 
 // `count` MSMs of n pairs with host-resident scalars on device context c: the bases come from c's pinned copy of
 // key[lo .. lo + n) when there is one (with its window table), else they are uploaded.
-static int msm_shard_host(Ctx* c, const uint64_t* const* scalars, const uint64_t* bases_xy, size_t lo, size_t n, size_t count, XYZZ* out) {
+static int msm_shard_host(Ctx* c, const uint64_t* const* scalars, const uint64_t* bases_xy, size_t lo, size_t n, size_t count, XYZZ* out,
+                          bool use_cache = true) {
     std::vector<const Fe*> sc(count);
     for (size_t j = 0; j < count; j++) sc[j] = (const Fe*)scalars[j] + lo;
     MsmTable tab;
     const Affine *d_bases = nullptr, *h_bases = nullptr;
     const MsmTable* t = nullptr;
     auto it = c->pinned.find((const void*)bases_xy);
-    if (it != c->pinned.end() && it->second.lo <= lo && lo + n <= it->second.hi) {
+    if (use_cache && it != c->pinned.end() && it->second.lo <= lo && lo + n <= it->second.hi) {
         const PinnedBases& pb = it->second;
         d_bases = (const Affine*)pb.d + (lo - pb.lo);
         if (pb.c) {
@@ -821,53 +899,51 @@ static int msm_shard_host(Ctx* c, const uint64_t* const* scalars, const uint64_t
     return msm_batch_device(c, sc.data(), true, d_bases, n, count, out, c->stream, t, h_bases);
 }
 
-// The partials of the devices meet: RCCL all-gather of 96 B per (device, MSM) as bytes when the engine holds
-// communicators, through host memory otherwise; then the left fold of arithmetic.rs:153 on the host (a lone GPU lane
-// needs ~6 us per group addition, a host core 0.5 us).  parts: [device][count] on the host already.
-static int gather_fold(int n_use, size_t count, const std::vector<std::vector<XYZZ>>& parts, uint64_t* out_xyz) {
-    std::vector<Jac> all((size_t)n_use * count);
-    for (int d = 0; d < n_use; d++)
-        for (size_t j = 0; j < count; j++) all[(size_t)d * count + j] = xyzz_to_jac(parts[(size_t)d][j]);
-    if (!g_rccl.comms.empty() && n_use == (int)g_devs.size()) {
-        const size_t bytes = count * sizeof(Jac);
-        int rc = on_devices(n_use, [&](int d) -> int {
-            Ctx* x = g_devs[(size_t)d];
-            int r = x->gather.ensure(bytes * (size_t)(n_use + 1));
-            if (r) return r;
-            return x->stage_h2d(x->gather.p, &all[(size_t)d * count], bytes, x->stream);
-        });
-        if (rc) return rc;
-        ncclResult_t nr = g_rccl.GroupStart();
-        for (int d = 0; nr == ncclSuccess && d < n_use; d++) {
-            Ctx* x = g_devs[(size_t)d];
-            nr = g_rccl.AllGather(x->gather.p, (char*)x->gather.p + bytes, bytes, ncclUint8, g_rccl.comms[(size_t)d], x->stream);
-        }
-        ncclResult_t ne = g_rccl.GroupEnd();
-        if (nr == ncclSuccess) nr = ne;
-        if (nr != ncclSuccess) {
-            set_error("ncclAllGather failed: %s", g_rccl.GetErrorString(nr));
-            return H2HIP_EDEVICE;
-        }
-        Ctx* c0 = g_devs[0];
-        H2_CHECK(hipSetDevice(c0->device));
-        H2_CHECK(hipMemcpyAsync(all.data(), (char*)c0->gather.p + bytes, bytes * (size_t)n_use, hipMemcpyDeviceToHost, c0->stream));
-        H2_CHECK(hipStreamSynchronize(c0->stream));
-        for (int d = 1; d < n_use; d++) {  // every rank's collective has drained before the buffers are reused
-            H2_CHECK(hipSetDevice(g_devs[(size_t)d]->device));
-            H2_CHECK(hipStreamSynchronize(g_devs[(size_t)d]->stream));
-        }
-        H2_CHECK(hipSetDevice(c0->device));
-    }
+// The partials of the devices meet on the host: every device's run has already returned its sums through pinned memory (the
+// call is synchronous), so the left fold of arithmetic.rs:153 is n_use - 1 additions on numbers the calling thread holds.
+static void fold_host(int n_use, size_t count, const std::vector<std::vector<XYZZ>>& parts, uint64_t* out_xyz) {
     for (size_t j = 0; j < count; j++) {
         XYZZ acc = xyzz_identity();
-        for (int d = 0; d < n_use; d++) xyzz_add(acc, jac_to_xyzz(all[(size_t)d * count + j]));
+        for (int d = 0; d < n_use; d++) xyzz_add(acc, parts[(size_t)d][j]);
         xyzz_to_out(acc, out_xyz + 12 * j);
     }
+}
+
+// HALO2_HIP_GATHER=rccl (fixed-base form only: one set sum per MSM): the sums stage C left in every device's `gather` buffer
+// (Ctx::gather_want) are all-gathered device to device over xGMI -- 128 B per (device, MSM), ncclUint8, one group call --
+// copied down once from the first device and folded on the host.  all[d * count + j] = sum of MSM j on device d.
+// Any failure leaves `all` untouched; the caller then folds the host copies instead.
+static int gather_rccl(size_t count, std::vector<XYZZ>* all) {
+    const int nd = (int)g_devs.size();
+    const size_t bytes = count * sizeof(XYZZ);
+    if (g_rccl.comms.size() != (size_t)nd || bytes > H2_GATHER_OWN) return H2HIP_EINVAL;
+    ncclResult_t nr = g_rccl.GroupStart();
+    for (int d = 0; nr == ncclSuccess && d < nd; d++) {
+        Ctx* x = g_devs[(size_t)d];
+        nr = g_rccl.AllGather(x->gather.p, (char*)x->gather.p + H2_GATHER_OWN, bytes, ncclUint8, g_rccl.comms[(size_t)d], x->stream);
+    }
+    ncclResult_t ne = g_rccl.GroupEnd();
+    if (nr == ncclSuccess) nr = ne;
+    if (nr != ncclSuccess) {
+        set_error("ncclAllGather failed: %s", g_rccl.GetErrorString(nr));
+        return H2HIP_EDEVICE;
+    }
+    std::vector<XYZZ> got((size_t)nd * count);
+    Ctx* c0 = g_devs[0];
+    H2_CHECK(hipSetDevice(c0->device));
+    H2_CHECK(hipMemcpyAsync(got.data(), (char*)c0->gather.p + H2_GATHER_OWN, bytes * (size_t)nd, hipMemcpyDeviceToHost, c0->stream));
+    H2_CHECK(hipStreamSynchronize(c0->stream));
+    for (int d = 1; d < nd; d++) {  // every rank's collective has drained before the buffers are reused
+        H2_CHECK(hipSetDevice(g_devs[(size_t)d]->device));
+        H2_CHECK(hipStreamSynchronize(g_devs[(size_t)d]->stream));
+    }
+    H2_CHECK(hipSetDevice(c0->device));
+    all->swap(got);
     return 0;
 }
 
 static int msm_host_common(const uint64_t* const* scalars, const uint64_t* bases_xy, size_t n, size_t count, uint64_t* out_xyz) {
-    Entry en("h2hip_msm_bn254");
+    Entry en("h2hip_msm_bn254", nullptr, true);
     if (en.rc) return en.rc;
     Ctx* c = en.c;
     if (n == 0 || count == 0) {
@@ -876,12 +952,12 @@ static int msm_host_common(const uint64_t* const* scalars, const uint64_t* bases
     }
     // a pinned entry whose fingerprint no longer matches the caller's array is stale (the allocation was freed and
     // reused): drop it on every device and fall back to uploading
-    pinned_validate(bases_xy, n);
+    const bool use_cache = pinned_validate(bases_xy, n);
     lazy_pin_consider(bases_xy, n);
     const int nd = (int)g_devs.size();
-    if (nd == 1 || n < g_cfg.multi_gpu_min_n) {
+    if (nd == 1 || n < g_cfg.multi_gpu_min_n || !use_cache) {
         std::vector<XYZZ> r(count);
-        int rc = msm_shard_host(c, scalars, bases_xy, 0, n, count, r.data());
+        int rc = msm_shard_host(c, scalars, bases_xy, 0, n, count, r.data(), use_cache);
         if (rc) return rc;
         for (size_t j = 0; j < count; j++) xyzz_to_out(r[j], out_xyz + 12 * j);
         return 0;
@@ -905,13 +981,42 @@ static int msm_host_common(const uint64_t* const* scalars, const uint64_t* bases
         }
     }
     std::vector<std::vector<XYZZ>> parts((size_t)nd, std::vector<XYZZ>(count, xyzz_identity()));
+    // RCCL gather only when asked for, communicators exist and every device runs the fixed-base form over its pinned share
+    bool use_rccl = g_cfg.gather_rccl && g_rccl.comms.size() == (size_t)nd && count * sizeof(XYZZ) <= H2_GATHER_OWN;
+    for (int d = 0; use_rccl && d < nd; d++) {
+        auto it = g_devs[(size_t)d]->pinned.find((const void*)bases_xy);
+        const bool idle = hi[(size_t)d] == lo[(size_t)d];
+        if (!idle && (it == g_devs[(size_t)d]->pinned.end() || !it->second.c)) use_rccl = false;
+    }
     int rc = on_devices(nd, [&](int d) -> int {
+        Ctx* x = g_devs[(size_t)d];
         const size_t m = hi[(size_t)d] - lo[(size_t)d];
-        if (!m) return 0;
-        return msm_shard_host(g_devs[(size_t)d], scalars, bases_xy, lo[(size_t)d], m, count, parts[(size_t)d].data());
+        x->gather_want = false;
+        x->gather_off = 0;
+        if (use_rccl) {
+            int r = x->gather.ensure(H2_GATHER_OWN * (size_t)(nd + 1));
+            if (r) return r;
+            H2_CHECK(hipMemsetAsync(x->gather.p, 0, count * sizeof(XYZZ), x->stream));  // an idle device contributes identities
+            x->gather_want = true;
+        }
+        int r = m ? msm_shard_host(x, scalars, bases_xy, lo[(size_t)d], m, count, parts[(size_t)d].data()) : 0;
+        x->gather_want = false;
+        return r;
     });
     if (rc) return rc;
-    return gather_fold(nd, count, parts, out_xyz);
+    if (use_rccl) {
+        for (int d = 0; d < nd; d++)
+            if (hi[(size_t)d] != lo[(size_t)d] && g_devs[(size_t)d]->gather_off != count * sizeof(XYZZ)) use_rccl = false;  // not one run per device
+    }
+    if (use_rccl) {
+        std::vector<XYZZ> all;
+        if (gather_rccl(count, &all) == 0) {
+            for (int d = 0; d < nd; d++)
+                for (size_t j = 0; j < count; j++) parts[(size_t)d][j] = all[(size_t)d * count + j];
+        }  // else: the host copies are complete and correct -- fold those
+    }
+    fold_host(nd, count, parts, out_xyz);
+    return 0;
 }
 
 int h2hip_msm_bn254(const uint64_t* scalars, const uint64_t* bases_xy, size_t n, uint64_t out_xyz[12]) {
@@ -948,9 +1053,7 @@ int h2hip_msm_bn254_batch_device(const void* const* d_scalars, const void* d_bas
     Entry en("h2hip_msm_bn254_batch_device", count ? d_scalars[0] : nullptr);
     if (en.rc) return en.rc;
     std::vector<XYZZ> r(count);
-    MsmTable tab;
-    const MsmTable* t = (n && count) ? pinned_table(en.c, d_bases_xy, n, nullptr, &tab) : nullptr;
-    int rc = msm_batch_device(en.c, (const Fe* const*)d_scalars, false, (const Affine*)d_bases_xy, n, count, r.data(), (hipStream_t)stream, t);
+    int rc = msm_device_keyed(en.c, (const Fe* const*)d_scalars, (const Affine*)d_bases_xy, n, count, r.data(), (hipStream_t)stream);
     if (rc) return rc;
     for (size_t j = 0; j < count; j++) xyzz_to_out(r[j], out_xyz + 12 * j);
     return 0;
@@ -965,6 +1068,7 @@ static int pin_on_device(Ctx* c, const void* key, const uint64_t* h_points, cons
     if (it != c->pinned.end()) {
         H2_CHECK(hipDeviceSynchronize());
         (void)hipFree(it->second.d);
+        if (it->second.d_sample) (void)hipFree(it->second.d_sample);
         c->pinned.erase(it);
     }
     if (hi <= lo) return 0;
@@ -999,12 +1103,23 @@ static int pin_on_device(Ctx* c, const void* key, const uint64_t* h_points, cons
         H2_CHECK(hipMemcpyAsync(pb.d, (const Affine*)h_points + lo, n * sizeof(Affine), hipMemcpyHostToDevice, c->stream));
     }
     if (cw) rc = msm_table_build(c, d_src ? (const Affine*)d_src + lo : (const Affine*)pb.d, n, cw, (Affine*)pb.d, c->stream);
+    if (!rc && device_key) {  // the fingerprint of a device key stays on the device
+        if (hipMalloc(&pb.d_sample, H2_PIN_SAMPLES * sizeof(Affine)) != hipSuccess) {
+            (void)hipGetLastError();
+            pb.d_sample = nullptr;
+            set_error("bases_pin: hipMalloc of the fingerprint failed");
+            rc = H2HIP_ENOMEM;
+        } else {
+            hipLaunchKernelGGL(pin_sample_kernel, dim3(1), dim3(64), 0, c->stream, (const Affine*)d_src + lo, n, (Affine*)pb.d_sample);
+        }
+    }
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) {
         set_error("bases_pin: table build failed");
         rc = H2HIP_EDEVICE;
     }
     if (rc) {
         (void)hipFree(pb.d);
+        if (pb.d_sample) (void)hipFree(pb.d_sample);
         return rc;
     }
     pb.c = cw;
@@ -1014,10 +1129,7 @@ static int pin_on_device(Ctx* c, const void* key, const uint64_t* h_points, cons
 }
 
 static void pin_sample(const uint64_t* bases_xy, size_t n, uint8_t* out) {
-    for (size_t k = 0; k < H2_PIN_SAMPLES; k++) {
-        const size_t i = H2_PIN_SAMPLES > 1 ? (size_t)((unsigned __int128)(n - 1) * k / (H2_PIN_SAMPLES - 1)) : 0;
-        memcpy(out + 64 * k, bases_xy + 8 * i, 64);
-    }
+    for (uint32_t k = 0; k < H2_PIN_SAMPLES; k++) memcpy(out + 64 * k, bases_xy + 8 * pin_sample_index(n, k), 64);
 }
 
 // pin a host array on every device (its contiguous share each): the body of h2hip_bases_pin, also reached by the lazy cache
@@ -1040,7 +1152,7 @@ int h2hip_bases_pin(const uint64_t* bases_xy, size_t n) {
         set_error("bases_pin: null/empty");
         return H2HIP_EINVAL;
     }
-    Entry en("h2hip_bases_pin");
+    Entry en("h2hip_bases_pin", nullptr, true);
     if (en.rc) return en.rc;
     lazy_forget((const void*)bases_xy);  // an explicit pin is the caller's to unpin
     return pin_host_everywhere(bases_xy, n);
@@ -1149,7 +1261,14 @@ int h2hip_bases_pin_device(const void* d_bases_xy, size_t n, void* stream) {
 }
 
 int h2hip_bases_unpin(const void* bases_xy) {
-    Entry en("h2hip_bases_unpin");
+    {
+        std::shared_lock<std::shared_mutex> eng(g_engine_mu);
+        if (!ctx()->ready) {  // nothing can be pinned; do not start the engine for this (interpreter teardown after h2hip_shutdown)
+            set_error("bases_unpin: pointer was not pinned (engine not initialised)");
+            return H2HIP_EINVAL;
+        }
+    }
+    Entry en("h2hip_bases_unpin", nullptr, true);
     if (en.rc) return en.rc;
     lazy_forget(bases_xy);
     if (!unpin_everywhere(bases_xy)) {
@@ -1166,23 +1285,41 @@ int h2hip_debug_rccl_gather_selftest(const uint64_t* partials_xyz, size_t count,
         set_error("rccl_gather_selftest: null argument");
         return H2HIP_EINVAL;
     }
-    Entry en("h2hip_debug_rccl_gather_selftest");
+    Entry en("h2hip_debug_rccl_gather_selftest", nullptr, true);
     if (en.rc) return en.rc;
     int rc = rccl_comms_create();
     if (rc) return rc;
     const int nd = (int)g_devs.size();
+    if (count * sizeof(XYZZ) > H2_GATHER_OWN) {
+        set_error("rccl_gather_selftest: at most %zu partials", H2_GATHER_OWN / sizeof(XYZZ));
+        return H2HIP_EINVAL;
+    }
+    std::vector<XYZZ> mine(count);
+    for (size_t j = 0; j < count; j++) {
+        Jac jc;
+        memcpy(&jc, partials_xyz + 12 * j, 96);
+        mine[j] = jac_to_xyzz(jc);
+    }
+    rc = on_devices(nd, [&](int d) -> int {  // stands in for stage C of a run: the device's sums land in its gather buffer
+        Ctx* x = g_devs[(size_t)d];
+        int r = x->gather.ensure(H2_GATHER_OWN * (size_t)(nd + 1));
+        if (r) return r;
+        H2_CHECK(hipMemcpyAsync(x->gather.p, mine.data(), count * sizeof(XYZZ), hipMemcpyHostToDevice, x->stream));
+        H2_CHECK(hipStreamSynchronize(x->stream));
+        return 0;
+    });
+    if (rc) return rc;
+    std::vector<XYZZ> all;
+    if ((rc = gather_rccl(count, &all))) return rc;
     std::vector<std::vector<XYZZ>> parts((size_t)nd, std::vector<XYZZ>(count));
     for (int d = 0; d < nd; d++)
-        for (size_t j = 0; j < count; j++) {
-            Jac jc;
-            memcpy(&jc, partials_xyz + 12 * j, 96);
-            parts[(size_t)d][j] = jac_to_xyzz(jc);
-        }
-    return gather_fold(nd, count, parts, out_xyz);
+        for (size_t j = 0; j < count; j++) parts[(size_t)d][j] = all[(size_t)d * count + j];
+    fold_host(nd, count, parts, out_xyz);
+    return 0;
 }
 
 int h2hip_bases_pinned_info(const void* bases_xy, size_t* n_points, uint32_t* window_bits, uint32_t* windows, size_t* device_bytes) {
-    Entry en;
+    Entry en(nullptr, nullptr, true);
     if (en.rc) return en.rc;
     size_t n = 0, bytes = 0;
     uint32_t c = 0, W = 0;
@@ -1491,24 +1628,79 @@ static int batch_args_ok(void* const* d_a, size_t count, uint32_t log_n, const c
     return 1;
 }
 
+// SURVEY.md 8(e), second bullet: NTTs are single-GPU, but independent transforms (the coset NTTs of
+// plonk/evaluation.rs:306-323) can run on several GPUs as whole columns.  A batch whose columns all live on one engine device
+// runs there, asynchronously on the caller's stream, under that device's lock only.  A batch whose columns live on SEVERAL
+// engine devices is split by owner: each device transforms its own columns as one batch on its engine stream, the groups run
+// concurrently (one host thread per device), and the call returns when all of them are done (the caller's stream is
+// synchronised first).  No column crosses xGMI: the caller decides the placement.  With the same device listed twice
+// (HALO2_HIP_ALLOW_DUPLICATE_DEVICES, rehearsal) the columns of that device are dealt round-robin to its contexts.
+static int batch_over_devices(const char* name, void* const* d_a, size_t count, void* stream, uint32_t log_n, const Fe& omega, const NttScale* sc) {
+    if (!count) return 0;
+    std::vector<int> owner(count, 0);
+    bool mixed = false;
+    {
+        Entry en(name, d_a[0]);
+        if (en.rc) return en.rc;
+        const int nd = (int)g_devs.size();
+        if (nd > 1) {
+            std::vector<int> next_dup((size_t)nd, 0);
+            for (size_t i = 0; i < count; i++) {
+                hipPointerAttribute_t at;
+                if (hipPointerGetAttributes(&at, d_a[i]) != hipSuccess) {
+                    (void)hipGetLastError();
+                    set_error("%s: column %zu is not a device pointer", name, i);
+                    return H2HIP_EINVAL;
+                }
+                std::vector<int> cand;
+                for (int d = 0; d < nd; d++)
+                    if (g_devs[(size_t)d]->device == at.device) cand.push_back(d);
+                if (cand.empty()) {
+                    set_error("%s: column %zu lives on device %d, which is not in h2hip_init's list", name, i, at.device);
+                    return H2HIP_EINVAL;
+                }
+                owner[i] = cand[(size_t)(next_dup[(size_t)cand[0]]++) % cand.size()];
+                if (owner[i] != owner[0]) mixed = true;
+            }
+        }
+        if (!mixed) return ntt_device_batch(en.c, (Fe* const*)d_a, nullptr, count, omega, log_n, sc, (hipStream_t)stream);
+    }
+    Entry en(name, nullptr, true);  // several devices: all their locks, in list order
+    if (en.rc) return en.rc;
+    const int nd = (int)g_devs.size();
+    for (size_t i = 0; i < count; i++)
+        if (owner[i] >= nd) {
+            set_error("%s: the engine was re-initialised during the call", name);
+            return H2HIP_EINVAL;
+        }
+    H2_CHECK(hipStreamSynchronize((hipStream_t)stream));  // the columns may have been produced on the caller's stream
+    std::vector<std::vector<Fe*>> cols((size_t)nd);
+    for (size_t i = 0; i < count; i++) cols[(size_t)owner[i]].push_back((Fe*)d_a[i]);
+    return on_devices(nd, [&](int d) -> int {
+        Ctx* x = g_devs[(size_t)d];
+        if (cols[(size_t)d].empty()) return 0;
+        H2_CHECK(hipSetDevice(x->device));
+        int rc = ntt_device_batch(x, cols[(size_t)d].data(), nullptr, cols[(size_t)d].size(), omega, log_n, sc, x->stream);
+        if (rc) return rc;
+        H2_CHECK(hipStreamSynchronize(x->stream));
+        return 0;
+    });
+}
+
 int h2hip_ntt_bn254_fr_batch_device(void* const* d_a, size_t count, const uint64_t omega[4], uint32_t log_n, void* stream) {
     if (!omega || !batch_args_ok(d_a, count, log_n, "ntt_batch")) return H2HIP_EINVAL;
     if (check_fr(omega, "omega")) return H2HIP_EINVAL;
-    Entry en("h2hip_ntt_bn254_fr_batch_device", count ? d_a[0] : nullptr);
-    if (en.rc) return en.rc;
-    return ntt_device_batch(en.c, (Fe* const*)d_a, nullptr, count, fe_from_u64x4(omega), log_n, nullptr, (hipStream_t)stream);
+    return batch_over_devices("h2hip_ntt_bn254_fr_batch_device", d_a, count, stream, log_n, fe_from_u64x4(omega), nullptr);
 }
 
 int h2hip_ifft_bn254_fr_batch_device(void* const* d_a, size_t count, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4],
                                      void* stream) {
     if (!omega_inv || !divisor || !batch_args_ok(d_a, count, log_n, "ifft_batch")) return H2HIP_EINVAL;
     if (check_fr(omega_inv, "omega_inv") || check_fr(divisor, "divisor")) return H2HIP_EINVAL;
-    Entry en("h2hip_ifft_bn254_fr_batch_device", count ? d_a[0] : nullptr);
-    if (en.rc) return en.rc;
     NttScale sc;
     sc.out_scale = true;
     sc.out3[0] = sc.out3[1] = sc.out3[2] = fe_from_u64x4(divisor);
-    return ntt_device_batch(en.c, (Fe* const*)d_a, nullptr, count, fe_from_u64x4(omega_inv), log_n, &sc, (hipStream_t)stream);
+    return batch_over_devices("h2hip_ifft_bn254_fr_batch_device", d_a, count, stream, log_n, fe_from_u64x4(omega_inv), &sc);
 }
 
 int h2hip_coeff_to_extended_bn254_fr_batch_device(void* const* d_a, size_t count, uint32_t k, uint32_t extended_k, const uint64_t extended_omega[4],
@@ -1516,12 +1708,10 @@ int h2hip_coeff_to_extended_bn254_fr_batch_device(void* const* d_a, size_t count
     if (!extended_omega || !g_coset || !g_coset_inv || k > extended_k || !batch_args_ok(d_a, count, extended_k, "coeff_to_extended_batch"))
         return H2HIP_EINVAL;
     if (check_fr(extended_omega, "extended_omega") || check_fr(g_coset, "g_coset") || check_fr(g_coset_inv, "g_coset_inv")) return H2HIP_EINVAL;
-    Entry en("h2hip_coeff_to_extended_bn254_fr_batch_device", count ? d_a[0] : nullptr);
-    if (en.rc) return en.rc;
     NttScale sc;
     make_zeta_scale(&sc, true, g_coset, g_coset_inv, nullptr);
     sc.in_len = 1ull << k;
-    return ntt_device_batch(en.c, (Fe* const*)d_a, nullptr, count, fe_from_u64x4(extended_omega), extended_k, &sc, (hipStream_t)stream);
+    return batch_over_devices("h2hip_coeff_to_extended_bn254_fr_batch_device", d_a, count, stream, extended_k, fe_from_u64x4(extended_omega), &sc);
 }
 
 int h2hip_g_to_lagrange_bn254_device(const void* d_g_xy, uint32_t k, void* d_g_lagrange_xy, void* stream) {
@@ -1744,6 +1934,7 @@ int h2hip_debug_set_reserved_cus(uint32_t k) {
 
 int h2hip_profile_enable(int on) {
     Ctx* c = ctx();
+    std::shared_lock<std::shared_mutex> eng(g_engine_mu);
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     c->profiling = on == 1;
     c->profiling_kernel = on == 2;
@@ -1752,6 +1943,7 @@ int h2hip_profile_enable(int on) {
 
 int h2hip_profile_reset(void) {
     Ctx* c = ctx();
+    std::shared_lock<std::shared_mutex> eng(g_engine_mu);
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     c->timers_collect();
     c->timers.clear();
@@ -1764,6 +1956,7 @@ int h2hip_profile_get(const char* stage, double* total_ms, uint64_t* count) {
         return H2HIP_EINVAL;
     }
     Ctx* c = ctx();
+    std::shared_lock<std::shared_mutex> eng(g_engine_mu);
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     c->timers_collect();
     *total_ms = 0.0;

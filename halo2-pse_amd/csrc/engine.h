@@ -72,16 +72,23 @@ struct MsmTable {
     uint32_t c = 0, W = 0;
 };
 
+#define H2_GATHER_OWN ((size_t)64 << 10)  // bytes of Ctx::gather a device's own set sums may take; the gathered ones follow
 #define H2_PIN_SAMPLES 16
+// index of fingerprint sample k of an array of `total` points
+static inline __host__ __device__ size_t pin_sample_index(size_t total, uint32_t k) { return k == 0 ? 0 : (total - 1) >> (H2_PIN_SAMPLES - 1 - k); }
 // One entry of the pinned-bases cache, keyed by the caller's pointer (host or device).
 struct PinnedBases {
     void* d = nullptr;         // device copy: W x n points with the window table, or n points without one
     size_t n = 0;              // points per row
     uint32_t c = 0, W = 0;     // window width of the table; 0: no table (rows = 1)
-    bool device_key = false;   // the key is a device pointer (h2hip_bases_pin_device): no fingerprint check
-    // fingerprint of the host array at pin time: H2_PIN_SAMPLES points (first, last, evenly spread), compared byte for
-    // byte on every lookup -- a freed-and-reused allocation at the same address must not hit the stale copy
+    bool device_key = false;   // the key is a device pointer (h2hip_bases_pin_device)
+    // fingerprint of the caller's array at pin time: H2_PIN_SAMPLES points (pin_sample_index: the first one and a geometric
+    // ladder up to the last, so that every prefix length still sees several), compared byte for byte on every lookup -- a
+    // freed-and-reused allocation at the same address must not hit the stale copy.  Host keys: compared on the host
+    // (pinned_validate); device keys: d_sample holds the same bytes in device memory and a one-wave kernel ahead of the MSM
+    // compares them with the caller's buffer (pin_check_kernel), its verdict is read when the MSM's own result arrives.
     uint8_t sample[H2_PIN_SAMPLES * 64];
+    void* d_sample = nullptr;
     size_t lo = 0, hi = 0;     // multi-GPU: this device holds points [lo, hi) of the caller's array (n = hi - lo)
 };
 
@@ -102,6 +109,7 @@ struct Ctx {
     std::recursive_mutex mu;       // serialises entry points: re-entrant callers (rayon workers) are safe
     DevBuf ntt_ws, ntt_io, msm_scalars[3], msm_bases, msm_slot[3], misc, evalh_ws, evalh_slots, ecfft_ws, ntt_ptrs, gather, gen_table;
     HostBuf host_ws;               // pinned host memory for the window sums coming back
+    HostBuf pin_flag;              // one word the device-key fingerprint check writes its verdict to
     // Small host tables the kernels read (pointer lists, constants) go through this pinned ring, so that the
     // asynchronous copy never reads a caller's stack or a std::vector that is gone by the time the DMA runs.
     HostBuf stage;
@@ -133,6 +141,10 @@ struct Ctx {
     std::vector<hipEvent_t> aux_events;
     int ensure_aux(size_t n_events);
     Copier* copier = nullptr;  // created on first use, joined by copier_stop (release_ctx)
+    // multi-device engine, HALO2_HIP_GATHER=rccl: stage C also leaves the run's set sums in `gather` (device memory), from where
+    // ncclAllGather takes them; gather_off counts the bytes left there by this call (SIZE_MAX / 2 and up: not one run, unusable)
+    bool gather_want = false;
+    size_t gather_off = 0;
 };
 
 void copier_stop(Ctx* c);

@@ -1219,6 +1219,12 @@ static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_sums, hip
     H2_CHECK(hipGetLastError());
     c->timer_end(t4, s);
     H2_CHECK(hipMemcpyAsync(h_sums, sums, (size_t)ns * sizeof(XYZZ), hipMemcpyDeviceToHost, s));
+    if (c->gather_want) {  // the same sums stay on the device for the RCCL gather of a multi-device MSM (api.hip gather_rccl)
+        const size_t bytes = (size_t)ns * sizeof(XYZZ);
+        if (c->gather_off + bytes <= H2_GATHER_OWN && c->gather.p)
+            H2_CHECK(hipMemcpyAsync((char*)c->gather.p + c->gather_off, sums, bytes, hipMemcpyDeviceToDevice, s));
+        c->gather_off += bytes;
+    }
     return 0;
 }
 
@@ -1662,6 +1668,7 @@ int msm_batch_device(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, c
     const size_t max_chunk = g_max_chunk;
     std::vector<const Fe*> ptrs(count);
     std::vector<XYZZ> part(count);
+    if (n > max_chunk) c->gather_off = SIZE_MAX / 2;  // several runs per MSM: their sums are added on the host
     for (size_t o = 0; o < n; o += max_chunk) {
         size_t m = n - o < max_chunk ? n - o : max_chunk;
         for (size_t j = 0; j < count; j++) ptrs[j] = d_scalars[j] + o;

@@ -87,8 +87,9 @@ int h2hip_msm_bn254(const uint64_t* scalars, const uint64_t* bases_xy, size_t n,
  * Pinning also builds the fixed-base window table 2^(pos_j) * P_i (pos_j = first bit of window j, W = ceil(255/c) windows; n <= 2^26; W * n * 64
  * bytes of HBM, e.g. 0.8 GB at 2^20, 12 GB at 2^24): all windows of an MSM then share one bucket set, the
  * windows are wider (c = 20 instead of 16 at 2^20) and no Horner pass is needed.
- * The cache is safe against stale pointers: every lookup compares 16 sampled points of the caller's array
- * with the ones seen at pin time and falls back to a plain upload (dropping the entry) on a mismatch. */
+ * The cache is safe against stale pointers: every lookup compares 16 sampled points of the caller's array (the first
+ * point and a geometric ladder of indices up to the last, so that a shorter prefix still sees several) with the ones seen
+ * at pin time and falls back to a plain upload (dropping the entry) on a mismatch. */
 int h2hip_bases_pin(const uint64_t* bases_xy, size_t n);
 /* The lazy cache (HALO2_HIP_LAZY_PIN=k): for the unpatched two-line drop-in, whose best_multiexp(coeffs, bases) has no
  * handle in its signature.  A host array that reaches h2hip_msm_bn254[_batch] unpinned for the k-th time with the same
@@ -96,9 +97,14 @@ int h2hip_bases_pin(const uint64_t* bases_xy, size_t n);
  * dropped first; h2hip_bases_unpin removes one, h2hip_shutdown all).  Lookups validate it like any pinned entry.  What the
  * samples cannot see is a caller rewriting part of a live array in place; ParamsKZG never does, hence opt-in. */
 uint32_t h2hip_lazy_pin_after(void);
-/* the same for points that already live in HBM (keyed by the device pointer, used by the _device MSMs);
- * the points are copied, the caller's buffer is not referenced after the call returns */
+/* the same for points that already live in HBM (keyed by the device pointer, used by the _device MSMs).  The points are
+ * copied into the table, but the caller's buffer stays the KEY: keep it alive and unchanged until h2hip_bases_unpin, as a
+ * ParamsKZG keeps g.  Should it be freed and its address reused all the same, the cache notices: a one-wave kernel ahead
+ * of every MSM compares 16 sampled points of the buffer with the ones seen at pin time (no extra synchronisation; the
+ * verdict is read with the MSM's result), and on a mismatch the entry is dropped and the MSM runs over the caller's points. */
 int h2hip_bases_pin_device(const void* d_bases_xy, size_t n, void* stream);
+/* drops a pinned host array or device buffer; H2HIP_EINVAL when the pointer is not pinned (also when the engine is not
+ * initialised: the call never starts it) */
 int h2hip_bases_unpin(const void* bases_xy);
 /* what a pinned pointer holds: points, window width / windows of its table (0 / 0 without one), bytes of HBM */
 int h2hip_bases_pinned_info(const void* bases_xy, size_t* n_points, uint32_t* window_bits, uint32_t* windows, size_t* device_bytes);

@@ -161,15 +161,73 @@ def test_device_pinned_entry_points(h2, oracle):
         for j, col in enumerate(cols):
             w = oracle.g1_to_affine(oracle.best_multiexp(h2.to_numpy_u64(col), bs, NT))
             assert np.array_equal(aff(h2, got[j]), w), j
-        # the copy is the engine's own: overwriting the caller's buffer afterwards changes nothing
-        dp2 = dp.clone()
-        dp.zero_()
-        torch.cuda.synchronize()
-        assert np.array_equal(aff(h2, h2.msm_device(ds, dp)), want)
-        dp.copy_(dp2)
     finally:
         h2.bases_unpin_device(dp)
     assert np.array_equal(aff(h2, h2.msm_device(ds, dp)), want)  # plain form again
+
+
+def test_device_pinned_cache_detects_a_reused_address(h2, oracle):
+    """the device address is the cache key, and torch's caching allocator hands a freed address out
+    again readily.  A buffer whose contents changed under a pinned key (same address, other points: what a freed and
+    reused allocation looks like) must cost a miss, never the old table's commitment -- single and batched entry points,
+    a prefix of the array, and a real free + reallocate at the same address."""
+    import torch
+    n = 1 << 13
+    ds = h2.gen_scalars_device(0x5EED0001, n)
+    dp = h2.gen_points_device(0x5EED0002, n)
+    other = h2.gen_points_device(0x5EED0042, n)
+    sc = h2.to_numpy_u64(ds)
+    want_old = oracle.g1_to_affine(oracle.best_multiexp(sc, h2.to_numpy_u64(dp), NT))
+    want_new = oracle.g1_to_affine(oracle.best_multiexp(sc, h2.to_numpy_u64(other), NT))
+    h2.bases_pin_device(dp)
+    assert np.array_equal(aff(h2, h2.msm_device(ds, dp)), want_old)
+    dp.copy_(other)
+    torch.cuda.synchronize()
+    assert np.array_equal(aff(h2, h2.msm_device(ds, dp)), want_new)
+    with pytest.raises(h2.H2HipError):  # the lookup dropped the stale entry
+        h2.bases_unpin_device(dp)
+    # batched entry point, and a prefix shorter than the pinned array (only the samples below n are compared)
+    h2.bases_pin_device(dp)
+    cols = [h2.gen_scalars_device(70 + j, n) for j in range(3)]
+    got = h2.msm_batch_device(cols, dp)
+    dp.copy_(h2.gen_points_device(0x5EED0043, n))
+    torch.cuda.synchronize()
+    bs3 = h2.to_numpy_u64(dp)
+    got3 = h2.msm_batch_device(cols, dp)
+    for j in range(3):
+        assert not np.array_equal(got3[j], got[j])
+        assert np.array_equal(aff(h2, got3[j]), oracle.g1_to_affine(oracle.best_multiexp(h2.to_numpy_u64(cols[j]), bs3, NT))), j
+    h2.bases_pin_device(dp)
+    dp[:64].copy_(other[:64])  # the head of the array changes: a 1000-pair prefix sees it
+    torch.cuda.synchronize()
+    bs4 = h2.to_numpy_u64(dp)
+    assert np.array_equal(aff(h2, h2.msm_device(ds, dp, n=1000)), oracle.g1_to_affine(oracle.best_multiexp(sc[:1000], bs4[:1000], NT)))
+    # a real free + reallocation: the next tensor of the same size lands on the same address (caching allocator)
+    h2.bases_pin_device(dp)
+    addr = dp.data_ptr()
+    keep_alive = h2._device_pins.pop(addr)  # take the Python-side finalizer out of the picture: only the library's guard is left
+    keep_alive.detach()
+    del dp
+    dq = h2.gen_points_device(0x5EED0044, n)
+    if dq.data_ptr() == addr:
+        assert np.array_equal(aff(h2, h2.msm_device(ds, dq)), oracle.g1_to_affine(oracle.best_multiexp(sc, h2.to_numpy_u64(dq), NT)))
+    else:  # the allocator chose another block: drop the orphan entry by its address
+        import ctypes
+        assert h2.lib().h2hip_bases_unpin(ctypes.c_void_p(addr)) == 0
+
+
+def test_device_pin_follows_the_tensor_lifetime(h2):
+    """the Python wrapper ties the entry to the tensor (weakref.finalize): dropping the tensor unpins"""
+    import ctypes
+    import gc
+    dp = h2.gen_points_device(0x5EED0002, 1 << 10)
+    h2.bases_pin_device(dp)
+    addr = dp.data_ptr()
+    assert addr in h2._device_pins
+    del dp
+    gc.collect()
+    assert addr not in h2._device_pins
+    assert h2.lib().h2hip_bases_unpin(ctypes.c_void_p(addr)) != 0  # already gone
 
 
 @pytest.mark.parametrize("n,count", [(1 << 10, 200), (1 << 13, 200)])
@@ -287,6 +345,68 @@ if dup_allowed:
     got = h2.best_multiexp_batch(cols, bs)
     out["batch_equal"] = all(h2.g1_to_affine(got[j]).tolist() == oracle.g1_to_affine(oracle.best_multiexp(cols[j], bs, 8)).tolist() for j in range(3))
     h2.bases_unpin(bs)
+    # round 3: each device's shard streams in (chunk ladder into persistent buckets), pinned and unpinned
+    import ctypes
+    h2.lib().h2hip_debug_set_msm_stream(ctypes.c_uint32(3), ctypes.c_uint32(600), ctypes.c_size_t(4096))
+    out["stream_unpinned_equal"] = h2.g1_to_affine(h2.best_multiexp(sc, bs)).tolist() == want
+    h2.bases_pin(bs)
+    out["stream_pinned_equal"] = h2.g1_to_affine(h2.best_multiexp(sc, bs)).tolist() == want
+    got = h2.best_multiexp_batch(cols, bs)
+    out["stream_batch_equal"] = all(h2.g1_to_affine(got[j]).tolist() == oracle.g1_to_affine(oracle.best_multiexp(cols[j], bs, 8)).tolist() for j in range(3))
+    h2.bases_unpin(bs)
+    h2.lib().h2hip_debug_set_msm_stream(ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_size_t(0))
+    # round 3: batched transforms split by owning device (here: dealt round-robin to the two contexts of the one GPU), the
+    # groups run concurrently on their own host threads; results equal the one-column calls
+    import torch
+    k = 12
+    dom = h2.EvaluationDomain.new(4, k)
+    cols_h = [oracle.gen_scalars(900 + j, 1 << k, num_threads=8) for j in range(5)]
+    d_cols = [torch.from_numpy(c_.view(np.int64)).cuda() for c_ in cols_h]
+    h2.ntt_batch_device(d_cols, dom.omega, k)
+    torch.cuda.synchronize()
+    out["ntt_batch_equal"] = all(np.array_equal(h2.to_numpy_u64(d_cols[j]), oracle.best_fft(cols_h[j], dom.omega, k, 4)) for j in range(5))
+    h2.ifft_batch_device(d_cols, dom.omega_inv, k, dom.ifft_divisor)
+    torch.cuda.synchronize()
+    out["ifft_batch_roundtrip"] = all(np.array_equal(h2.to_numpy_u64(d_cols[j]), cols_h[j]) for j in range(5))
+    ext = [torch.zeros((1 << dom.extended_k) * 4, dtype=torch.int64, device="cuda") for _ in range(3)]
+    od, _ = oracle.domain_new(4, k)
+    for j in range(3):
+        ext[j][:(1 << k) * 4] = d_cols[j].reshape(-1)
+    h2.coeff_to_extended_batch_device(ext, k, dom.extended_k, dom.extended_omega, dom.g_coset, dom.g_coset_inv)
+    torch.cuda.synchronize()
+    out["coeff_to_extended_batch_equal"] = all(np.array_equal(h2.to_numpy_u64(ext[j]).reshape(-1, 4), oracle.coeff_to_extended(od, cols_h[j].copy(), 4)) for j in range(3))
+    # round 3: entry points from several threads at once (per-device locks; ctypes drops the GIL during the calls)
+    import threading
+    d_big = [h2.gen_scalars_device(77 + j, 1 << 16) for j in range(4)]
+    dp_t = h2.gen_points_device(78, 1 << 14)
+    ds_t = [h2.gen_scalars_device(79 + j, 1 << 14) for j in range(4)]
+    exp_ntt = []
+    dom16 = h2.EvaluationDomain.new(2, 16)
+    for t_ in d_big:
+        c_ = t_.clone()
+        h2.ntt_device(c_, dom16.omega, 16)
+        exp_ntt.append(h2.to_numpy_u64(c_).copy())
+    exp_msm = [h2.g1_to_affine(h2.msm_device(s_, dp_t)) for s_ in ds_t]  # the group element: Jacobian coordinates depend on the addition order
+    res = [None] * 8
+    def work_ntt(j):
+        for _ in range(5):
+            c_ = d_big[j].clone()
+            h2.ntt_device(c_, dom16.omega, 16)
+            torch.cuda.synchronize()
+            res[j] = bool(np.array_equal(h2.to_numpy_u64(c_), exp_ntt[j]))
+            if not res[j]:
+                return
+    def work_msm(j):
+        for _ in range(5):
+            res[4 + j] = bool(np.array_equal(h2.g1_to_affine(h2.msm_device(ds_t[j], dp_t)), exp_msm[j]))
+            if not res[4 + j]:
+                return
+    ths = [threading.Thread(target=work_ntt, args=(j,)) for j in range(4)] + [threading.Thread(target=work_msm, args=(j,)) for j in range(4)]
+    for t_ in ths:
+        t_.start()
+    for t_ in ths:
+        t_.join()
+    out["threads_ok"] = all(r_ is True for r_ in res)
     small = h2.g1_to_affine(h2.best_multiexp(sc[:100], bs[:100])).tolist()  # below the sharding threshold: device 0 only
     out["small_equal"] = small == oracle.g1_to_affine(oracle.best_multiexp(sc[:100], bs[:100], 8)).tolist()
     h2.shutdown()
@@ -318,7 +438,9 @@ def test_two_device_contexts_shard_fold_bit_exact():
     here; the ncclAllGather path needs distinct GPUs.)"""
     out = _run_multi({"HALO2_HIP_ALLOW_DUPLICATE_DEVICES": "1", "HALO2_HIP_MULTI_GPU_MIN_N": "1024"})
     assert out["dup"] == "accepted"
-    for key in ("sharded_equal", "sharded_odd_equal", "pinned_equal", "pinned_prefix_equal", "batch_equal", "small_equal", "after_reinit_equal"):
+    for key in ("sharded_equal", "sharded_odd_equal", "pinned_equal", "pinned_prefix_equal", "batch_equal", "small_equal", "after_reinit_equal",
+                "stream_unpinned_equal", "stream_pinned_equal", "stream_batch_equal", "ntt_batch_equal", "ifft_batch_roundtrip",
+                "coeff_to_extended_batch_equal", "threads_ok"):
         assert out[key] is True, (key, out)
     assert out["pinned_points"] == 1 << 16
 
