@@ -104,11 +104,9 @@ struct L1Args {
     const Fe* const* list;  // fused batch: MSM y reads list[y]
     uint32_t n, c, q, W, cb, L, C1;
     uint32_t shared, stride;  // fixed-base: entry index = window * stride + pair
-    uint32_t tile;                // scalars per workgroup of the scatter pass
-    uint32_t count_tile;          // scalars per workgroup of the count pass (multiple of 256)
-    uint32_t* g_cnt;              // [C1] coarse-bin sizes (count pass)
-    const uint32_t* coarse_start; // [C1 + 1] (scatter pass)
-    uint32_t* g_cursor;           // [C1] entries already reserved per coarse bin (scatter pass)
+    uint32_t tile;                // scalars per tile: one workgroup of the count pass and one of the scatter pass each
+    uint16_t* tile_hist;          // [tiles][C1] entries of the tile per coarse bin (count pass writes, scatter pass reads)
+    const uint32_t* tile_off;     // [tiles][C1] where the tile's run of each bin starts in tmp (scatter pass)
     uint2* tmp;                   // (entry, bucket id) grouped by coarse bin
 };
 
@@ -120,17 +118,24 @@ __device__ __forceinline__ Fe fr_to_canonical(const Fe& x) {
     return fu_mul_canon<FrU>(fu_slice(x), c32);
 }
 
-// A1: sizes of the coarse bins.  Bucket id of (MSM y, window w, slot) = (set << cb) | slot with set = y (fixed-base)
-// or y * W + w; coarse bin = bucket id >> L.
+// Level 1 is a counting sort by coarse bin (bucket id >> L) WITHOUT global atomics: the scalars are cut into tiles (one
+// workgroup of the count pass and one of the scatter pass each); the count pass leaves every tile's histogram in HBM, three
+// small kernels turn the [tiles][C1] matrix into every (tile, bin)'s offset (column-wise exclusive sums: tiles in chunks of
+// MSM_TCHUNK, then the chunks, then the bins), and the scatter pass writes its runs there.  With one atomic per (workgroup,
+// bin) instead -- non-returning in the count pass, returning in the scatter pass, 2 x 1 M of them at 2^20 pairs -- the atomics
+// WERE the two passes: they top out near 60 and 20 G/s chip-wide.  Bucket id of (MSM y, window w, slot) =
+// (set << cb) | slot with set = y (fixed-base) or y * W + w.
+#define MSM_TCHUNK 64u  // tiles per chunk of the offset computation
+
+// A1: histogram of the tile over the coarse bins
 __global__ void __launch_bounds__(256) msm_l1_count_kernel(L1Args a) {
     __shared__ uint32_t lh[MSM_MAX_C1];
     for (uint32_t b = threadIdx.x; b < a.C1; b += 256) lh[b] = 0;
     __syncthreads();
     const Fe* __restrict__ scalars = a.list ? a.list[blockIdx.y] : a.scalars_one;
     const uint32_t set0 = a.shared ? blockIdx.y : blockIdx.y * a.W;
-    const uint32_t i0 = blockIdx.x * a.count_tile + threadIdx.x;
-    for (uint32_t t = 0; t < a.count_tile / 256; t++) {
-        const uint32_t i = i0 + t * 256;
+    for (uint32_t t = threadIdx.x; t < a.tile; t += 256) {
+        const uint32_t i = blockIdx.x * a.tile + t;
         if (i < a.n) {
             const Fe sc = fr_to_canonical(scalars[i]);
             for_each_digit(sc, a.c, a.q, a.W, [&](uint32_t w, uint32_t slot, uint32_t) {
@@ -140,8 +145,20 @@ __global__ void __launch_bounds__(256) msm_l1_count_kernel(L1Args a) {
         }
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < a.C1; b += 256)
-        if (lh[b]) atomicAdd(&a.g_cnt[b], lh[b]);
+    uint16_t* row = a.tile_hist + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * a.C1;
+    for (uint32_t b = threadIdx.x; b < a.C1; b += 256) row[b] = (uint16_t)lh[b];  // a tile holds at most MSM_STAGE entries
+}
+
+// A2a: entries per (chunk of tiles, bin); lane = bin
+__global__ void __launch_bounds__(256) msm_l1_chunk_kernel(const uint16_t* __restrict__ tile_hist, uint32_t n_tiles, uint32_t C1,
+                                                           uint32_t* __restrict__ chunk_sum) {
+    const uint32_t b = blockIdx.y * 256 + threadIdx.x;
+    if (b >= C1) return;
+    const uint32_t t0 = blockIdx.x * MSM_TCHUNK, t1 = t0 + MSM_TCHUNK < n_tiles ? t0 + MSM_TCHUNK : n_tiles;
+    uint32_t sum = 0;
+#pragma unroll 8
+    for (uint32_t t = t0; t < t1; t++) sum += tile_hist[(size_t)t * C1 + b];
+    chunk_sum[(size_t)blockIdx.x * C1 + b] = sum;
 }
 
 // exclusive scan of cnt[0..n) over a workgroup of BS lanes (n <= per * BS): lane t owns elements [t * per, (t + 1) * per).
@@ -176,35 +193,28 @@ __device__ __forceinline__ uint32_t block_scan_base(const uint32_t* cnt, uint32_
 }
 
 // A3: one scalar per lane (the first a.tile lanes).  The workgroup sorts its entries by coarse bin in LDS and writes
-// every bin's share as one contiguous run.  What bounds this pass is how HBM takes the writes: with 3-entry runs (or a
-// scattered 8-byte store per entry) every run is a partial-line write and the pass ran at 0.6 TB/s; hence at most
-// MSM_MAX_C1 bins for a tile of up to MSM_STAGE entries.  One returning global atomic per (workgroup, bin) reserves
-// the run's place.
+// every bin's share as one contiguous run at the offset A2c computed for (tile, bin).  What bounds this pass is how HBM takes
+// the writes: with 3-entry runs (or a scattered 8-byte store per entry) every run is a partial-line write and the pass ran at
+// 0.6 TB/s; hence at most MSM_MAX_C1 bins for a tile of up to MSM_STAGE entries.
 __global__ void __launch_bounds__(1024) msm_l1_scatter_kernel(L1Args a) {
     __shared__ uint2 stage[MSM_STAGE];
     __shared__ uint32_t cur[MSM_MAX_C1];   // entries per bin, then the bin's cursor in `stage`
     __shared__ uint32_t delta[MSM_MAX_C1]; // (position in tmp) - (position in stage) of the bin's run (mod 2^32)
     __shared__ uint32_t ps[16];
-    for (uint32_t b = threadIdx.x; b < a.C1; b += 1024) cur[b] = 0;
-    __syncthreads();
+    const size_t row = (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * a.C1;
+    for (uint32_t b = threadIdx.x; b < a.C1; b += 1024) cur[b] = a.tile_hist[row + b];
     const Fe* __restrict__ scalars = a.list ? a.list[blockIdx.y] : a.scalars_one;
     const uint32_t set0 = a.shared ? blockIdx.y : blockIdx.y * a.W;
     const uint32_t i = blockIdx.x * a.tile + threadIdx.x;
     const bool live = threadIdx.x < a.tile && i < a.n;
     Fe sc;
-    if (live) {
-        sc = fr_to_canonical(scalars[i]);
-        for_each_digit(sc, a.c, a.q, a.W, [&](uint32_t w, uint32_t slot, uint32_t) {
-            const uint32_t gb = ((set0 + (a.shared ? 0u : w)) << a.cb) | slot;
-            atomicAdd(&cur[gb >> a.L], 1u);
-        });
-    }
+    if (live) sc = fr_to_canonical(scalars[i]);
     __syncthreads();
     uint32_t total;
     uint32_t run = block_scan_base<1024>(cur, a.C1, 1, ps, &total);  // C1 <= 1024: one bin per lane
     if (threadIdx.x < a.C1) {
-        const uint32_t b = threadIdx.x, cnt = cur[b];
-        if (cnt) delta[b] = a.coarse_start[b] + atomicAdd(&a.g_cursor[b], cnt) - run;
+        const uint32_t b = threadIdx.x;
+        delta[b] = a.tile_off[row + b] - run;
         cur[b] = run;
     }
     __syncthreads();
@@ -222,13 +232,66 @@ __global__ void __launch_bounds__(1024) msm_l1_scatter_kernel(L1Args a) {
     }
 }
 
-// A2: coarse_start = exclusive scan of the C1 <= 1024 coarse-bin sizes; one workgroup of 1024
-__global__ void __launch_bounds__(1024) msm_l1_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t C1, uint32_t* __restrict__ coarse_start) {
-    __shared__ uint32_t ps[16];
+// A2b: exclusive sums down the chunks (in place) and the total of every bin.  Workgroup = 64 bins x 16 parts of the chunk list
+// (a lone lane per bin walking 256 chunks at 2^24 pairs took 39 us).
+__global__ void __launch_bounds__(1024) msm_l1_scan_kernel(uint32_t* __restrict__ chunk_sum, uint32_t n_chunks, uint32_t C1,
+                                                           uint32_t* __restrict__ bin_total) {
+    __shared__ uint32_t part_sum[16][64];
+    const uint32_t lb = threadIdx.x & 63, p = threadIdx.x >> 6, b = blockIdx.x * 64 + lb;
+    const uint32_t per = (n_chunks + 15) / 16, c0 = p * per, c1 = c0 + per < n_chunks ? c0 + per : n_chunks;
+    uint32_t sum = 0;
+    if (b < C1)
+        for (uint32_t ch = c0; ch < c1; ch++) sum += chunk_sum[(size_t)ch * C1 + b];
+    part_sum[p][lb] = sum;
+    __syncthreads();
+    uint32_t acc = 0, all = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 16; q++) {
+        const uint32_t v = part_sum[q][lb];
+        if (q < p) acc += v;
+        all += v;
+    }
+    if (b < C1) {
+        for (uint32_t ch = c0; ch < c1; ch++) {
+            const uint32_t v = chunk_sum[(size_t)ch * C1 + b];
+            chunk_sum[(size_t)ch * C1 + b] = acc;
+            acc += v;
+        }
+        if (p == 0) bin_total[b] = all;
+    }
+}
+
+// A2c: tile_off[t][b] = coarse_start[b] + (entries of bin b in the tiles before t); lane = bin, one chunk of tiles per workgroup.
+// coarse_start = exclusive scan of the C1 <= 1024 bin totals, which every workgroup forms for itself in LDS (the first column
+// of workgroups also writes it out for level 2).
+__global__ void __launch_bounds__(256) msm_l1_offsets_kernel(const uint16_t* __restrict__ tile_hist, uint32_t n_tiles, uint32_t C1,
+                                                             const uint32_t* __restrict__ chunk_sum, const uint32_t* __restrict__ bin_total,
+                                                             uint32_t* __restrict__ coarse_start, uint32_t* __restrict__ tile_off) {
+    __shared__ uint32_t cs[MSM_MAX_C1], ps[4];
+    const uint32_t per = (C1 + 255) / 256;
     uint32_t total;
-    const uint32_t run = block_scan_base<1024>(cnt, C1, 1, ps, &total);
-    if (threadIdx.x < C1) coarse_start[threadIdx.x] = run;
-    if (threadIdx.x == 0) coarse_start[C1] = total;
+    uint32_t run = block_scan_base<256>(bin_total, C1, per, ps, &total);
+    for (uint32_t j = 0; j < per; j++) {
+        const uint32_t k = threadIdx.x * per + j;
+        if (k < C1) {
+            cs[k] = run;
+            run += bin_total[k];
+        }
+    }
+    __syncthreads();
+    const uint32_t b = blockIdx.y * 256 + threadIdx.x;
+    if (b >= C1) return;
+    if (blockIdx.x == 0) {
+        coarse_start[b] = cs[b];
+        if (b == 0) coarse_start[C1] = total;
+    }
+    const uint32_t t0 = blockIdx.x * MSM_TCHUNK, t1 = t0 + MSM_TCHUNK < n_tiles ? t0 + MSM_TCHUNK : n_tiles;
+    uint32_t running = cs[b] + chunk_sum[(size_t)blockIdx.x * C1 + b];
+#pragma unroll 8
+    for (uint32_t t = t0; t < t1; t++) {
+        tile_off[(size_t)t * C1 + b] = running;
+        running += tile_hist[(size_t)t * C1 + b];
+    }
 }
 
 // size classes of the accumulate order: 256 classes of width 2^bin_shift entries, big buckets first
@@ -916,12 +979,13 @@ struct MsmLayout {
     size_t n, E;        // pairs per MSM; upper bound of the entries of the run
     uint32_t K;         // buckets in total
     uint32_t L, C1, bin_shift;
+    uint32_t tile, tiles_x, n_tiles, n_tchunks;  // level-1 tiling: scalars per tile, tiles per MSM, tiles and tile chunks of the run
     uint32_t split_log;  // lanes per bucket of the accumulation = 2^split_log
     // reduction: levels 0..2 of row/column passes before the final kernel
     uint32_t levels, s, rb, s2, s3;
     size_t max_chunks, max_heavy;
-    size_t o_zero, o_zero_end, o_ccnt, o_ccur, o_hist, o_hcnt, o_cstart, o_tmp, o_vals, o_start, o_counts, o_perm, o_buckets, o_parts, o_RA, o_CA, o_RR,
-        o_RC, o_CR, o_CC, o_sums, o_partials, o_hb, o_hc, o_hs, o_ptrs, total;
+    size_t o_zero, o_zero_end, o_bintot, o_hist, o_hcnt, o_cstart, o_tmp, o_vals, o_start, o_counts, o_perm, o_buckets, o_parts, o_RA, o_CA, o_RR,
+        o_RC, o_CR, o_CC, o_sums, o_partials, o_hb, o_hc, o_hs, o_ptrs, o_thist, o_toff, o_chsum, total;
 };
 
 // force_c / force_split: the chunks of a streamed MSM (msm_stream_host) all use the window width and the lanes-per-bucket
@@ -964,6 +1028,11 @@ static int msm_layout(size_t n, MsmLayout* L, uint32_t fuse, const MsmTable* tab
     }
     L->L = Lb;
     L->C1 = (uint32_t)(K64 >> Lb);
+    L->tile = (MSM_STAGE / p.W) & ~63u;  // tile * W entries fit the LDS stage of the scatter pass
+    if (L->tile > 1024) L->tile = 1024;
+    L->tiles_x = (uint32_t)((n + L->tile - 1) / L->tile);
+    L->n_tiles = L->tiles_x * fuse;
+    L->n_tchunks = (L->n_tiles + MSM_TCHUNK - 1) / MSM_TCHUNK;
     // size classes: width 2^bin_shift entries, the mean bucket size lands in classes 50..100 (of 256)
     L->bin_shift = 0;
     const size_t mean_bucket = (p.shared ? n * p.W : n) >> p.cb;
@@ -988,13 +1057,12 @@ static int msm_layout(size_t n, MsmLayout* L, uint32_t fuse, const MsmTable* tab
     const size_t E = L->E;
     const uint32_t K = L->K, ns = L->n_sets;
     // -- plan-sized regions (offsets independent of n)
-    L->o_zero = off;  // one memset clears: coarse counts, coarse cursors, heavy counters
-    L->o_ccnt = carve((size_t)MSM_MAX_C1 * 4);
-    L->o_ccur = carve((size_t)MSM_MAX_C1 * 4);
+    L->o_zero = off;  // one memset clears: size-class histogram and cursors, heavy counters
     L->o_hist = carve(512 * 4);
     L->o_hcnt = carve(16);
     L->o_zero_end = off;
     L->o_cstart = carve(((size_t)MSM_MAX_C1 + 1) * 4);
+    L->o_bintot = carve((size_t)MSM_MAX_C1 * 4);
     L->o_start = carve((size_t)K * 4);
     L->o_counts = carve((size_t)K * 4);
     L->o_perm = carve((size_t)K * 4);
@@ -1010,6 +1078,9 @@ static int msm_layout(size_t n, MsmLayout* L, uint32_t fuse, const MsmTable* tab
     L->o_partials = carve((size_t)ns * 16 * sizeof(XYZZu));
     L->o_ptrs = carve((size_t)fuse * sizeof(void*));
     // -- regions sized by the entries of the run
+    L->o_thist = carve((size_t)L->n_tiles * L->C1 * 2);
+    L->o_toff = carve((size_t)L->n_tiles * L->C1 * 4);
+    L->o_chsum = carve((size_t)L->n_tchunks * L->C1 * 4);
     L->o_tmp = carve(E * 8);
     L->o_vals = carve(E * 4);
     L->o_hb = carve(L->max_heavy * sizeof(HeavyBucket));
@@ -1023,7 +1094,7 @@ static int msm_layout(size_t n, MsmLayout* L, uint32_t fuse, const MsmTable* tab
 static int msm_stage_a(Ctx* c, const MsmLayout& L, char* base, const Fe* const* d_scalars_list, const MsmTable* tab, hipStream_t s) {
     const MsmPlan& p = L.p;
     const size_t n = L.n;
-    uint32_t *ccnt = (uint32_t*)(base + L.o_ccnt), *ccur = (uint32_t*)(base + L.o_ccur), *cstart = (uint32_t*)(base + L.o_cstart);
+    uint32_t* cstart = (uint32_t*)(base + L.o_cstart);
     uint32_t *vals = (uint32_t*)(base + L.o_vals), *start = (uint32_t*)(base + L.o_start);
     uint32_t *counts = (uint32_t*)(base + L.o_counts), *perm = (uint32_t*)(base + L.o_perm);
     int t0 = c->timer_begin("msm_digits", s);
@@ -1045,22 +1116,25 @@ static int msm_stage_a(Ctx* c, const MsmLayout& L, char* base, const Fe* const* 
     a.C1 = L.C1;
     a.shared = p.shared;
     a.stride = tab ? (uint32_t)tab->stride : 0;
-    a.tile = (MSM_STAGE / p.W) & ~63u;  // scalars per scatter workgroup: tile * W entries fit the LDS stage
-    if (a.tile > 1024) a.tile = 1024;
-    a.g_cnt = ccnt;
-    a.coarse_start = cstart;
-    a.g_cursor = ccur;
+    a.tile = L.tile;
+    a.tile_hist = (uint16_t*)(base + L.o_thist);
+    a.tile_off = (const uint32_t*)(base + L.o_toff);
     a.tmp = (uint2*)(base + L.o_tmp);
-    // one non-returning global atomic per (workgroup, bin): large tiles where there are many workgroups anyway, small
-    // ones where the pass would otherwise be a handful of workgroups walking 16 scalars per lane
-    a.count_tile = n * L.fuse >= ((size_t)1 << 22) ? MSM_COUNT_TILE : 1024;
-    hipLaunchKernelGGL(msm_l1_count_kernel, dim3((uint32_t)((n + a.count_tile - 1) / a.count_tile), L.fuse), dim3(256), 0, s, a);
+    uint32_t* chsum = (uint32_t*)(base + L.o_chsum);
+    const dim3 tiles(L.tiles_x, L.fuse), chunks(L.n_tchunks, (L.C1 + 255) / 256);
+    hipLaunchKernelGGL(msm_l1_count_kernel, tiles, dim3(256), 0, s, a);
     H2_CHECK(hipGetLastError());
     c->timer_end(t0, s);
     int t1 = c->timer_begin("msm_sort", s);
-    hipLaunchKernelGGL(msm_l1_scan_kernel, dim3(1), dim3(1024), 0, s, ccnt, L.C1, cstart);
+    hipLaunchKernelGGL(msm_l1_chunk_kernel, chunks, dim3(256), 0, s, (const uint16_t*)a.tile_hist, L.n_tiles, L.C1, chsum);
     H2_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(msm_l1_scatter_kernel, dim3((uint32_t)((n + a.tile - 1) / a.tile), L.fuse), dim3(1024), 0, s, a);
+    uint32_t* bin_total = (uint32_t*)(base + L.o_bintot);
+    hipLaunchKernelGGL(msm_l1_scan_kernel, dim3((L.C1 + 63) / 64), dim3(1024), 0, s, chsum, L.n_tchunks, L.C1, bin_total);
+    H2_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(msm_l1_offsets_kernel, chunks, dim3(256), 0, s, (const uint16_t*)a.tile_hist, L.n_tiles, L.C1, (const uint32_t*)chsum,
+                       (const uint32_t*)bin_total, cstart, (uint32_t*)(base + L.o_toff));
+    H2_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(msm_l1_scatter_kernel, tiles, dim3(1024), 0, s, a);
     H2_CHECK(hipGetLastError());
     uint32_t* hist = (uint32_t*)(base + L.o_hist);
     hipLaunchKernelGGL(msm_l2_kernel, dim3(L.C1), dim3(1024), 0, s, (const uint2*)(base + L.o_tmp), cstart, L.L, L.bin_shift, vals, start, counts, perm,
