@@ -227,6 +227,27 @@ FR_ZETA = 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23
 _FR_R = (1 << 256) % FR_MODULUS
 
 
+class PrimeField:
+    """what EvaluationDomain::new needs of `G::Scalar` (ff::PrimeField + FieldExt): modulus, 2-adicity S, ROOT_OF_UNITY
+    (a primitive 2^S-th root), ZETA (a primitive cube root), and the 4 x u64 Montgomery limbs (R = 2^256) of an integer"""
+
+    def __init__(self, name, modulus, S, root_of_unity, zeta):
+        self.name, self.modulus, self.S, self.root_of_unity, self.zeta = name, modulus, S, root_of_unity, zeta
+        self._R = (1 << 256) % modulus
+
+    def from_int(self, v):
+        m = (int(v) % self.modulus) * self._R % self.modulus
+        return np.array([(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+BN254_FR = PrimeField("bn256::Fr", FR_MODULUS, FR_S, FR_ROOT_OF_UNITY, FR_ZETA)
+# pasta_curves Fp (the scalar field of vesta / EqAffine, the curve of the reference's pinned verification key in
+# tests/plonk_api.rs:624-632): multiplicative generator 5, 2-adicity 32, ROOT_OF_UNITY = 5^((p - 1) / 2^32), ZETA a cube root
+# of unity (5^((p - 1) / 3); which of the two the crate fixes is not visible in the reference and does not enter omega).
+_PASTA_P = 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001
+PASTA_FP = PrimeField("pasta::Fp", _PASTA_P, 32, pow(5, (_PASTA_P - 1) >> 32, _PASTA_P), pow(5, (_PASTA_P - 1) // 3, _PASTA_P))
+
+
 def fr_from_int(v):
     """integer -> the 4 x u64 Montgomery limbs the reference stores"""
     m = (int(v) % FR_MODULUS) * _FR_R % FR_MODULUS
@@ -253,27 +274,35 @@ class EvaluationDomain:
         for f in self.FIELDS:
             setattr(self, f, _fe(consts[f]))
         self.t_evaluations = None if t_evaluations is None else _u64(t_evaluations, 4)
+        self.field = BN254_FR
+
+    def _device_field(self):
+        if self.field is not BN254_FR:
+            raise H2HipError("the engine transforms bn256::Fr only (domain over %s)" % self.field.name)
 
     @classmethod
-    def new(cls, j, k):
-        """EvaluationDomain::new (poly/domain.rs:39-142)"""
-        r = FR_MODULUS
+    def new(cls, j, k, field=None):
+        """EvaluationDomain::new (poly/domain.rs:39-142), generic over the scalar field as the reference is (`G::Scalar`):
+        `field` is a PrimeField (default BN254_FR, the only field the device entry points serve; PASTA_FP exists so that the
+        constructor can be checked against the one domain constant the reference's own tests pin, tests/plonk_api.rs:629-632)."""
+        field = BN254_FR if field is None else field
+        r = field.modulus
         quotient_poly_degree = j - 1                                    # :41
         n = 1 << k                                                      # :44
         extended_k = k                                                  # :49-52
         while (1 << extended_k) < n * quotient_poly_degree:
             extended_k += 1
-        if extended_k > FR_S:
-            raise ValueError("extended_k exceeds the 2-adicity of Fr")
-        extended_omega = FR_ROOT_OF_UNITY                               # :54-61
-        for _ in range(extended_k, FR_S):
+        if extended_k > field.S:
+            raise ValueError("extended_k exceeds the 2-adicity of the field")
+        extended_omega = field.root_of_unity                            # :54-61
+        for _ in range(extended_k, field.S):
             extended_omega = extended_omega * extended_omega % r
         omega = extended_omega                                          # :70-73
         for _ in range(k, extended_k):
             omega = omega * omega % r
-        g_coset = FR_ZETA                                               # :81
+        g_coset = field.zeta                                            # :81
         g_coset_inv = g_coset * g_coset % r                             # :82
-        orig = pow(FR_ZETA, n, r)                                       # :84-107
+        orig = pow(field.zeta, n, r)                                    # :84-107
         step = pow(extended_omega, n, r)
         t_evaluations, cur = [], orig
         while True:
@@ -288,9 +317,11 @@ class EvaluationDomain:
             "extended_omega_inv": pow(extended_omega, -1, r), "g_coset": g_coset, "g_coset_inv": g_coset_inv,
             "ifft_divisor": pow(1 << k, -1, r), "extended_ifft_divisor": pow(1 << extended_k, -1, r),   # :109-110
         }
-        d = cls(k, extended_k, quotient_poly_degree, t_evaluations=np.stack([fr_from_int(c) for c in t_evaluations]),
-                **{f: fr_from_int(v) for f, v in consts.items()})
-        d.barycentric_weight = fr_from_int(pow(n, -1, r))               # :114
+        d = cls(k, extended_k, quotient_poly_degree, t_evaluations=np.stack([field.from_int(c) for c in t_evaluations]),
+                **{f: field.from_int(v) for f, v in consts.items()})
+        d.barycentric_weight = field.from_int(pow(n, -1, r))            # :114
+        d.field = field
+        d.ints = dict(consts)  # the same constants as integers (canonical form)
         return d
 
     def extended_len(self):
@@ -298,6 +329,7 @@ class EvaluationDomain:
 
     def lagrange_to_coeff(self, a):
         """poly/domain.rs:226-236"""
+        self._device_field()
         a = _u64(a, 4).copy()
         assert a.shape[0] == 1 << self.k
         _check(lib().h2hip_ifft_bn254_fr(_p(a), _p(self.omega_inv), ctypes.c_uint32(self.k), _p(self.ifft_divisor)),
@@ -306,6 +338,7 @@ class EvaluationDomain:
 
     def coeff_to_extended(self, a):
         """poly/domain.rs:240-254"""
+        self._device_field()
         a = _u64(a, 4)
         assert a.shape[0] == 1 << self.k
         out = np.zeros((self.extended_len(), 4), dtype=np.uint64)
@@ -316,6 +349,7 @@ class EvaluationDomain:
 
     def extended_to_coeff(self, a):
         """poly/domain.rs:281-303 (including the truncate at :299-300)"""
+        self._device_field()
         a = _u64(a, 4).copy()
         assert a.shape[0] == self.extended_len()
         _check(lib().h2hip_extended_to_coeff_bn254_fr(_p(a), ctypes.c_uint32(self.extended_k), _p(self.extended_omega_inv),
@@ -326,6 +360,7 @@ class EvaluationDomain:
 
     def divide_by_vanishing_poly(self, a, t_evaluations=None):
         """poly/domain.rs:307-326"""
+        self._device_field()
         a = _u64(a, 4).copy()
         t = self.t_evaluations if t_evaluations is None else _u64(t_evaluations, 4)
         assert a.shape[0] == self.extended_len()

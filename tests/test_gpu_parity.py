@@ -373,6 +373,54 @@ def test_msm_2p24_shard_fold_property(h2, oracle):
     assert np.array_equal(aff(h2, parts[0]), oracle.g1_to_affine(oracle.best_multiexp(sc, bs, NT)))
 
 
+def test_msm_2p24_fixed_base_equals_eight_oracle_checked_shards(h2, oracle):
+    """VERDICT r2 gap: the fixed-base form at the width it uses from 2^23 pairs up (c = 22, 2^21 buckets, 12 windows) met the
+    oracle only at <= 1024 points.  Here at BASELINE.json configs[3]'s full size: EVERY one of the 8 plain-form shards (the
+    multi-GPU partition, 2^21 pairs each) is checked against the oracle, and the fixed-base MSM of all 2^24 pairs -- device
+    entry point and streamed host-pointer entry point -- must equal their fold."""
+    n = 1 << 24
+    ds = h2.gen_scalars_device(0x5EED0001, n)
+    dp = h2.gen_points_device(0x5EED0002, n)
+    per = n // 8
+    parts = []
+    for i in range(8):
+        part = h2.msm_device(ds[i * per:(i + 1) * per], dp[i * per:(i + 1) * per])
+        sc, bs = h2.to_numpy_u64(ds[i * per:(i + 1) * per]), h2.to_numpy_u64(dp[i * per:(i + 1) * per])
+        assert np.array_equal(aff(h2, part), oracle.g1_to_affine(oracle.best_multiexp(sc, bs, NT))), i
+        parts.append(part)
+    want = aff(h2, h2.g1_fold(np.stack(parts)))
+    h2.bases_pin_device(dp)
+    try:
+        assert h2.bases_pinned_info(dp)[1] == 22
+        assert np.array_equal(aff(h2, h2.msm_device(ds, dp)), want)
+    finally:
+        h2.bases_unpin_device(dp)
+    sc, bs = h2.to_numpy_u64(ds).copy(), h2.to_numpy_u64(dp).copy()
+    del ds, dp
+    h2.bases_pin(bs)
+    try:
+        assert np.array_equal(aff(h2, h2.best_multiexp(sc, bs)), want)  # chunks stream into one persistent bucket set
+    finally:
+        h2.bases_unpin(bs)
+
+
+def test_ntt_2p24_forward_and_inverse_vs_oracle(h2, oracle):
+    """VERDICT r2 gap: above 2^22 the NTT was covered by a round trip only, which a transform that is consistently wrong in a
+    way its inverse undoes would pass.  2^24 points, forward and scaled inverse, limb for limb against the oracle's best_fft
+    (a few seconds on the host's threads)."""
+    k = 24
+    d, _ = oracle.domain_new(2, k)
+    da = h2.gen_scalars_device(0x5EED0003, 1 << k)
+    a = h2.to_numpy_u64(da).copy()
+    h2.ntt_device(da, d.fe("omega"), k)
+    want = oracle.best_fft(a, d.fe("omega"), k, NT)
+    assert np.array_equal(h2.to_numpy_u64(da), want)
+    db = h2.gen_scalars_device(0x5EED0004, 1 << k)
+    b = h2.to_numpy_u64(db).copy()
+    h2.ifft_device(db, d.fe("omega_inv"), k, d.fe("ifft_divisor"))
+    assert np.array_equal(h2.to_numpy_u64(db), oracle.ifft(b, d.fe("omega_inv"), k, d.fe("ifft_divisor"), NT))
+
+
 @pytest.mark.parametrize("k", [24, 26])
 def test_ntt_large_roundtrip(h2, oracle, k):
     """metric range 2^20..2^26: NTT then iNTT returns the input (2 GiB at k = 26); linearity spot check"""
