@@ -105,14 +105,17 @@ def timed_msm(h2, ds, dp, reps, warm=2):
 
 def msm_roofline(n, accum_ms, workload=None):
     ach = MSM_BYTES_PER_PAIR * n / (accum_ms * 1e-3) / 1e9
+    traffic = pmc_traffic(workload) if workload else None
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-            "traffic": pmc_traffic(workload) if workload else None, "kernel": "msm_accum_kernel", "kernel_ms": accum_ms,
+            "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this workload; not measured by this run)"
+            if traffic is not None else None, "kernel": "msm_accum_kernel", "kernel_ms": accum_ms,
             "algorithmic_bytes_per_launch": MSM_BYTES_PER_PAIR * n}
 
 
 def inlib_child(args):
     """--inlib N: ONE process drives N GPUs through the C ABI -- h2hip_init(ids, N), host-pointer h2hip_msm_bn254 over bases
-    pinned across the devices, partials gathered with RCCL inside the library.  Prints one JSON object."""
+    pinned across the devices, every device's shard streaming in over its own PCIe link, partials folded on the host
+    (HALO2_HIP_GATHER=rccl: all-gathered over xGMI from the devices' HBM instead).  Prints one JSON object."""
     h2 = load_pkg()
     n_dev = args.inlib
     ids = list(range(n_dev))
@@ -143,7 +146,7 @@ def inlib_child(args):
     W = info[2]
     res = {"n_devices": n_dev, "device_ids": ids, "pairs_total": n, "window_bits": info[1], "windows": W, "pin_s": pin_s,
            "table_bytes_total": info[3], "ms_per_msm": t * 1e3, "value": n * W / t, "unit": "G1-adds/s", "pairs_per_s": n / t,
-           "gather": "host (duplicate device ids: rehearsal)" if len(set(ids)) < len(ids) else os.environ.get("HALO2_HIP_GATHER", "rccl"),
+           "gather": "host fold (duplicate device ids: rehearsal)" if len(set(ids)) < len(ids) else os.environ.get("HALO2_HIP_GATHER", "host") + " (HALO2_HIP_GATHER)",
            "note": "host-pointer h2hip_msm_bn254 (scalars cross PCIe inside the call: %d MiB per device), bases pinned per device" % ((32 << args.log_n) >> 20),
            "result_affine_x0": int(h2.g1_to_affine(out)[0])}
     h2.bases_unpin(bs)
@@ -406,6 +409,10 @@ def main():
         hp = {"msm_2p%d_unpinned_ms" % args.log_n: host_ms(lambda: h2.best_multiexp(sc, bs))}
         h2.bases_pin(bs)
         hp["msm_2p%d_pinned_ms" % args.log_n] = host_ms(lambda: h2.best_multiexp(sc, bs))
+        # the same call with the whole upload ahead of the run (round 2's path), for the gain of streaming
+        h2.lib().h2hip_debug_set_msm_stream(ctypes.c_uint32(1), ctypes.c_uint32(0), ctypes.c_size_t(0))
+        hp["msm_2p%d_pinned_no_streaming_ms" % args.log_n] = host_ms(lambda: h2.best_multiexp(sc, bs))
+        h2.lib().h2hip_debug_set_msm_stream(ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_size_t(0))
         h2.bases_unpin(bs)
         # the same unpatched call with HALO2_HIP_LAZY_PIN=2 (set here through the library's hook): the second sighting pins the array
         h2.lib().h2hip_debug_set_lazy_pin(ctypes.c_uint32(2))
@@ -417,10 +424,27 @@ def main():
                 h2.bases_unpin(bs)
             except h2.H2HipError:
                 pass
+        # BASELINE.json's north_star size through the same entry point: 2^24 pairs, 512 MiB of scalars crossing PCIe
+        del sc, bs
+        n24 = 1 << 24
+        ds24 = h2.gen_scalars_device(0x5EED0001, n24, device=dev)
+        dp24 = h2.gen_points_device(0x5EED0002, n24, device=dev)
+        sc, bs = h2.to_numpy_u64(ds24).copy(), h2.to_numpy_u64(dp24).copy()
+        h2.bases_pin_device(dp24)
+        ms24, _, r24 = timed_msm(h2, ds24, dp24, 3, warm=1)
+        h2.bases_unpin_device(dp24)
+        del ds24, dp24
+        torch.cuda.empty_cache()
+        h2.bases_pin(bs)
+        hp["msm_2p24_pinned_ms"] = host_ms(lambda: h2.best_multiexp(sc, bs), reps=3)
+        hp["msm_2p24_device_resident_ms"] = ms24
+        hp["msm_2p24_same_group_element"] = bool(np.array_equal(h2.g1_to_affine(h2.best_multiexp(sc, bs)), h2.g1_to_affine(r24)))
+        h2.bases_unpin(bs)
         dk = h2.EvaluationDomain.new(2, args.ntt_log_n)
         a = h2.to_numpy_u64(h2.gen_scalars_device(3, 1 << args.ntt_log_n, device=dev)).copy()
         hp["ntt_2p%d_ms" % args.ntt_log_n] = host_ms(lambda: h2.best_fft(a, dk.omega, args.ntt_log_n), reps=3)
-        hp["note"] = "h2hip_msm_bn254 / h2hip_ntt_bn254_fr with host pointers: the scalars (and, unpinned, the bases) cross PCIe inside the call; lazy_pin = no h2hip_bases_pin call, HALO2_HIP_LAZY_PIN=2"
+        hp["note"] = ("h2hip_msm_bn254 / h2hip_ntt_bn254_fr with host pointers (pageable caller memory): the scalars (and, unpinned, the bases) cross PCIe inside "
+                      "the call, in chunks that stream under the work; lazy_pin = no h2hip_bases_pin call, HALO2_HIP_LAZY_PIN=2")
         sizes["host_pointer"] = hp
         del sc, bs, a
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -495,17 +519,32 @@ def main():
                 env.pop(k_, None)
             if args.backend != "nccl":
                 env["HALO2_HIP_ALLOW_DUPLICATE_DEVICES"] = "1"
+            def run_inlib(extra_env, timeout):
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--inlib", str(world), "--log-n", str(args.log_n), "--steps", "7"],
+                                       capture_output=True, text=True, timeout=timeout, env=dict(env, **extra_env))
+                    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("INLIB ")]
+                    return json.loads(lines[-1][6:]) if lines else {"error": (r.stdout + r.stderr)[-600:]}
+                except subprocess.TimeoutExpired:
+                    return {"error": "timed out after %d s" % timeout}
+                except Exception as e:  # whatever happens here, the other ranks must be released
+                    return {"error": repr(e)[:300]}
+
             try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--inlib", str(world), "--log-n", str(args.log_n), "--steps", "7"],
-                                   capture_output=True, text=True, timeout=240, env=env)
-                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("INLIB ")]
-                inlib = json.loads(lines[-1][6:]) if lines else {"error": (r.stdout + r.stderr)[-600:]}
-            except subprocess.TimeoutExpired:
-                inlib = {"error": "timed out after 240 s"}
-            with open(marker, "w") as f:
-                f.write("done")
+                inlib = run_inlib({"HALO2_HIP_GATHER": "host"}, 240)
+                want_x0 = int(h2.g1_to_affine(result)[0])  # the ranks' shards are the same global sequence the child draws
+                if "result_affine_x0" in inlib:
+                    inlib["same_group_element_as_process_per_gpu"] = inlib["result_affine_x0"] == want_x0
+                if args.backend == "nccl" and "error" not in inlib:  # distinct GPUs: the xGMI exchange of the same call
+                    rc_ = run_inlib({"HALO2_HIP_GATHER": "rccl"}, 120)
+                    if "result_affine_x0" in rc_:
+                        rc_["same_group_element_as_process_per_gpu"] = rc_["result_affine_x0"] == want_x0
+                    inlib["gather_rccl"] = {k_: rc_.get(k_) for k_ in ("ms_per_msm", "gather", "same_group_element_as_process_per_gpu", "error") if k_ in rc_}
+            finally:
+                with open(marker, "w") as f:
+                    f.write("done")
         else:
-            stop = time.time() + 300
+            stop = time.time() + 420
             while not os.path.exists(marker) and time.time() < stop:
                 time.sleep(0.05)
         sync_all()
