@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """bench.py -- BN254 MSM (+ Fr NTT) throughput on MI355X, one process per GPU.
 
 Step = one pass of the hot path over one batch of synthetic input: one BN254 G1 MSM of

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """Golden vectors for Evaluator::evaluate_h (halo2_proofs/src/plonk/evaluation.rs:280-522), minted with Python
 big integers straight from the constraint formulas -- the gate Expression tree evaluated directly per row
 (Expression::evaluate semantics, evaluation.rs:755-786), the permutation and lookup constraints from the

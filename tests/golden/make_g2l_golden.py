@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """Golden vectors for g_to_lagrange (halo2_proofs/src/arithmetic.rs:277-301), minted from the definition with Python
 integers and naive affine curve arithmetic (no FFT): g_lagrange[i] = [1/n] * sum_j [omega^(-i*j)] g[j], where omega is
 the 2^k-th root of unity EvaluationDomain uses.  Inputs: random curve points, with the identity and a repeated point

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """Mint golden vectors for the BN254 MSM / Fr-NTT hot path with Python big integers.
 
 Independent of oracle/bn254_oracle.c and of the HIP code: everything here is plain

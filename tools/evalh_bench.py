@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """evaluate_h (plonk/evaluation.rs:280-522) on device-resident columns: time per call by HIP events, and the oracle on the
 host cores beside it.  The constraint system is synthetic but shaped like a mid-sized PLONKish circuit: `--gates` degree-4
 gate polynomials over `--advice` advice and `--fixed` fixed columns with rotations in [-2, 2], a permutation over

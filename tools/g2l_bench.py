@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """g_to_lagrange (arithmetic.rs:277-301) timing: device-resident call by HIP events, the oracle on the host cores beside it
 at a size it finishes in seconds.   python tools/g2l_bench.py --k 16 [--cpu-k 12]   (run on the GPU box)"""
 import argparse

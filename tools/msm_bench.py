@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """tools/msm_bench.py -- stage times of one device-resident MSM, plain form and fixed-base form (window table built by
 h2hip_bases_pin_device), for a list of sizes and optional window overrides.  Prints one JSON object per line."""
 import argparse

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """Column conversions of the SURVEY.md 3.4 call trace (k = 17: 10 iNTT 2^17, 10 coset NTT 2^17 -> 2^19), one call per column vs
 the batched entry points.  python tools/ntt_batch_bench.py [--k 17] [--cols 10]   (run on the GPU box)"""
 import argparse

@@ -2,6 +2,13 @@
 # tools/pmc_sq.sh NAME COUNTERS -- python3 PROGRAM ARGS   one --pmc pass (no trace), per-kernel mean of each counter
 set -e
 name=$1; ctrs=$2; shift; shift; shift
+# The program after `--` must be the interpreter binary itself (python3 PROGRAM ...): rocprofv3's preloaded library has the GPU
+# initialised before the program starts, so a hop through `env`, a shell or a `#!/usr/bin/env` script would exec from a process that
+# already holds the GPU -- forbidden on this pool.
+case "$(basename -- "$1")" in
+  python3|python|python3.*) ;;
+  *) echo "$0: run the interpreter directly after -- (python3 PROGRAM ARGS), not '$1'" >&2; exit 2;;
+esac
 export TMPDIR=/tmp
 mkdir -p gpurun_out/$name
 rocprofv3 --pmc $ctrs --output-format csv -d gpurun_out/$name -o p -- "$@" > gpurun_out/$name/run.log 2>&1 || { tail -20 gpurun_out/$name/run.log; exit 1; }

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """Per-kernel averages of two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, collected in separate runs as the MI355X
 guide prescribes) -> a table on stdout and gpurun_out/pmc_per_kernel.json.  Counter units are KiB (raw, uncorrected)."""
 import collections

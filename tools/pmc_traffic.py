@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as the MI355X guide's
 HBM section prescribes) into per-launch HBM bytes for one kernel and write profiles/pmc_traffic.json.
 

@@ -1,4 +1,4 @@
-#!/usr/bin/env python3
+#!/usr/bin/python3
 """The hot-path calls of one KZG proof of examples/circuit-layout.rs's MyCircuit at k = 17 (BASELINE.json
 configs[4]): 10 commit_lagrange + 6 commit of 2^17, 10 lagrange_to_coeff of 2^17, 10 coeff_to_extended 2^17 -> 2^19, one
 extended_to_coeff of 2^19 -- device-resident columns, timed call by call and through the batched entry points, with the
