@@ -234,9 +234,13 @@ __global__ void __launch_bounds__(1024) msm_l1_scatter_kernel(L1Args a) {
 
 // A2b: exclusive sums down the chunks (in place) and the total of every bin.  Workgroup = 64 bins x 16 parts of the chunk list
 // (a lone lane per bin walking 256 chunks at 2^24 pairs took 39 us).
+// Its first workgroup also clears the run's counters (size-class histogram, heavy counters, final-stage arrival counters): no
+// memset launch.
 __global__ void __launch_bounds__(1024) msm_l1_scan_kernel(uint32_t* __restrict__ chunk_sum, uint32_t n_chunks, uint32_t C1,
-                                                           uint32_t* __restrict__ bin_total) {
+                                                           uint32_t* __restrict__ bin_total, uint32_t* __restrict__ zero, uint32_t zero_words) {
     __shared__ uint32_t part_sum[16][64];
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < zero_words; i += 1024) zero[i] = 0;
     const uint32_t lb = threadIdx.x & 63, p = threadIdx.x >> 6, b = blockIdx.x * 64 + lb;
     const uint32_t per = (n_chunks + 15) / 16, c0 = p * per, c1 = c0 + per < n_chunks ? c0 + per : n_chunks;
     uint32_t sum = 0;
@@ -778,9 +782,13 @@ __global__ void __launch_bounds__(64) msm_rowcol_quad_kernel(RowColArgs args) {
     if (live && g == 0 && role == 0) J.out[task] = sh[quad];
 }
 
-// final, part 1: workgroup (set, group) scales 16 of the set's remaining points (one per quad) and sums them
-__global__ void __launch_bounds__(64) msm_final_quad_kernel(FinalArgs args, uint32_t n_groups, XYZZu* __restrict__ partials) {
+// final: workgroup (set, group) scales 16 of the set's remaining points (one per quad) and sums them; the workgroup that
+// arrives last for its set (arrival counter, cleared with the run's other counters) then sums the set's <= 16 partials -- the
+// second launch this used to be cost ~10 us of a lone MSM's latency chain.
+__global__ void __launch_bounds__(64) msm_final_quad_kernel(FinalArgs args, uint32_t n_groups, XYZZu* __restrict__ partials, uint32_t* __restrict__ done,
+                                                            XYZZ* __restrict__ set_sums) {
     __shared__ XYZZu sh[16];
+    __shared__ uint32_t is_last;
     const uint32_t set = blockIdx.x / n_groups, group = blockIdx.x - set * n_groups;
     const uint32_t quad = threadIdx.x >> 2, role = threadIdx.x & 3;
     uint32_t e = group * 16 + quad;  // index into the set's arrays laid end to end
@@ -818,15 +826,20 @@ __global__ void __launch_bounds__(64) msm_final_quad_kernel(FinalArgs args, uint
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
-}
-
-// final, part 2: one wave per set sums the <= 16 partials
-__global__ void __launch_bounds__(64) msm_final_sum_kernel(const XYZZu* __restrict__ partials, uint32_t n_groups, XYZZ* __restrict__ set_sums) {
-    __shared__ XYZZu sh[16];
-    const uint32_t quad = threadIdx.x >> 2, role = threadIdx.x & 3;
-    XYZZu x = xyzzu_identity();
-    if (quad < n_groups) x = partials[(size_t)blockIdx.x * n_groups + quad];
+    if (n_groups == 1) {
+        if (threadIdx.x == 0) set_sums[set] = xyzzu_to_ext(sh[0]);
+        return;
+    }
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = sh[0];
+        __threadfence();
+        is_last = atomicAdd(&done[set], 1u) == n_groups - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other workgroups' partials, written before their arrivals
+    x = xyzzu_identity();
+    if (quad < n_groups) x = partials[(size_t)set * n_groups + quad];
     if (role == 0) sh[quad] = x;
     __syncthreads();
     for (uint32_t st = 8; st >= 1; st >>= 1) {
@@ -837,7 +850,7 @@ __global__ void __launch_bounds__(64) msm_final_sum_kernel(const XYZZu* __restri
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) set_sums[blockIdx.x] = xyzzu_to_ext(sh[0]);
+    if (threadIdx.x == 0) set_sums[set] = xyzzu_to_ext(sh[0]);
 }
 
 // Fixed-base table, one step: out[i] = 2^c * prev[i] (XYZZ; normalised to affine by ec_normalize afterwards)
@@ -984,7 +997,7 @@ struct MsmLayout {
     // reduction: levels 0..2 of row/column passes before the final kernel
     uint32_t levels, s, rb, s2, s3;
     size_t max_chunks, max_heavy;
-    size_t o_zero, o_zero_end, o_bintot, o_hist, o_hcnt, o_cstart, o_tmp, o_vals, o_start, o_counts, o_perm, o_buckets, o_parts, o_RA, o_CA, o_RR,
+    size_t o_zero, o_zero_end, o_bintot, o_hist, o_hcnt, o_fdone, o_cstart, o_tmp, o_vals, o_start, o_counts, o_perm, o_buckets, o_parts, o_RA, o_CA, o_RR,
         o_RC, o_CR, o_CC, o_sums, o_partials, o_hb, o_hc, o_hs, o_ptrs, o_thist, o_toff, o_chsum, total;
 };
 
@@ -1057,9 +1070,10 @@ static int msm_layout(size_t n, MsmLayout* L, uint32_t fuse, const MsmTable* tab
     const size_t E = L->E;
     const uint32_t K = L->K, ns = L->n_sets;
     // -- plan-sized regions (offsets independent of n)
-    L->o_zero = off;  // one memset clears: size-class histogram and cursors, heavy counters
+    L->o_zero = off;  // cleared by msm_l1_scan_kernel: size-class histogram and cursors, heavy counters, arrivals per set of the final stage
     L->o_hist = carve(512 * 4);
     L->o_hcnt = carve(16);
+    L->o_fdone = carve((size_t)MSM_MAX_C1 * 4);
     L->o_zero_end = off;
     L->o_cstart = carve(((size_t)MSM_MAX_C1 + 1) * 4);
     L->o_bintot = carve((size_t)MSM_MAX_C1 * 4);
@@ -1098,7 +1112,6 @@ static int msm_stage_a(Ctx* c, const MsmLayout& L, char* base, const Fe* const* 
     uint32_t *vals = (uint32_t*)(base + L.o_vals), *start = (uint32_t*)(base + L.o_start);
     uint32_t *counts = (uint32_t*)(base + L.o_counts), *perm = (uint32_t*)(base + L.o_perm);
     int t0 = c->timer_begin("msm_digits", s);
-    H2_CHECK(hipMemsetAsync(base + L.o_zero, 0, L.o_zero_end - L.o_zero, s));
     L1Args a;
     a.scalars_one = d_scalars_list[0];
     a.list = nullptr;
@@ -1129,7 +1142,8 @@ static int msm_stage_a(Ctx* c, const MsmLayout& L, char* base, const Fe* const* 
     hipLaunchKernelGGL(msm_l1_chunk_kernel, chunks, dim3(256), 0, s, (const uint16_t*)a.tile_hist, L.n_tiles, L.C1, chsum);
     H2_CHECK(hipGetLastError());
     uint32_t* bin_total = (uint32_t*)(base + L.o_bintot);
-    hipLaunchKernelGGL(msm_l1_scan_kernel, dim3((L.C1 + 63) / 64), dim3(1024), 0, s, chsum, L.n_tchunks, L.C1, bin_total);
+    hipLaunchKernelGGL(msm_l1_scan_kernel, dim3((L.C1 + 63) / 64), dim3(1024), 0, s, chsum, L.n_tchunks, L.C1, bin_total,
+                       (uint32_t*)(base + L.o_zero), (uint32_t)((L.o_zero_end - L.o_zero) / 4));
     H2_CHECK(hipGetLastError());
     hipLaunchKernelGGL(msm_l1_offsets_kernel, chunks, dim3(256), 0, s, (const uint16_t*)a.tile_hist, L.n_tiles, L.C1, (const uint32_t*)chsum,
                        (const uint32_t*)bin_total, cstart, (uint32_t*)(base + L.o_toff));
@@ -1284,9 +1298,7 @@ static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_sums, hip
         for (uint32_t i = 0; i < fa.n_arr; i++) n_el += fa.arr[i].len;
         const uint32_t n_groups = (n_el + 15) / 16;  // <= 16: at most 4 arrays of 64
         XYZZu* partials = (XYZZu*)(base + L.o_partials);
-        hipLaunchKernelGGL(msm_final_quad_kernel, dim3(ns * n_groups), dim3(64), 0, s, fa, n_groups, partials);
-        H2_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(msm_final_sum_kernel, dim3(ns), dim3(64), 0, s, (const XYZZu*)partials, n_groups, sums);
+        hipLaunchKernelGGL(msm_final_quad_kernel, dim3(ns * n_groups), dim3(64), 0, s, fa, n_groups, partials, (uint32_t*)(base + L.o_fdone), sums);
     } else {
         hipLaunchKernelGGL(msm_final_kernel, dim3(ns), dim3(256), 0, s, fa, sums);
     }
