@@ -27,6 +27,9 @@ for it in range(int(os.environ.get("MSM_CASES", "24"))):
     elif kind == 3:
         sc[:] = sc[0]                                              # one scalar everywhere: every point lands in the same bucket per window
     want = oracle.g1_to_affine(oracle.best_multiexp(sc, bs, NT))
+    # round 3: the host-slice call streams in a random number of chunks (ladder ratio and threshold random too), or not at all
+    chunks = rng.choice([1, 2, 3, 4, 6])
+    L.h2hip_debug_set_msm_stream(ctypes.c_uint32(chunks), ctypes.c_uint32(rng.choice([300, 600, 1000, 1700])), ctypes.c_size_t(rng.choice([1024, 4096, 1 << 16])))
     got_plain = h2.g1_to_affine(h2.best_multiexp(sc, bs))
     h2.bases_pin(bs)
     try:
@@ -35,8 +38,19 @@ for it in range(int(os.environ.get("MSM_CASES", "24"))):
         h2.bases_unpin(bs)
     ok = np.array_equal(got_plain, want) and np.array_equal(got_fixed, want)
     bad += not ok
-    print("msm n=%d kind=%d %s" % (n, kind, "ok" if ok else "MISMATCH"), flush=True)
+    if n >= 2 and it % 3 == 0:  # and a batch of columns over the same bases (fused groups stream in)
+        cols = [sc, np.ascontiguousarray(sc[::-1]), oracle.gen_scalars(3000 + it, n, num_threads=NT)][:rng.choice([2, 3])]
+        h2.bases_pin(bs)
+        try:
+            gb = h2.best_multiexp_batch(cols, bs)
+        finally:
+            h2.bases_unpin(bs)
+        for j, col in enumerate(cols):
+            ok = ok and np.array_equal(h2.g1_to_affine(gb[j]), oracle.g1_to_affine(oracle.best_multiexp(col, bs, NT)))
+        bad += not ok and bad == 0
+    print("msm n=%d kind=%d chunks=%d %s" % (n, kind, chunks, "ok" if ok else "MISMATCH"), flush=True)
 
+L.h2hip_debug_set_msm_stream(ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_size_t(0))
 for k in range(1, 23):
     d = h2.EvaluationDomain.new(2, k)
     a = h2.gen_scalars_device(40 + k, 1 << k)
