@@ -27,6 +27,7 @@ void msm_set_max_chunk(size_t m);
 void msm_set_stream(uint32_t chunks, double ratio, size_t min_n);
 void msm_set_heavy_div(size_t d);
 void msm_set_bin_entries(size_t d);
+void msm_set_split_records(bool on);
 void msm_set_bucket_order(int local);
 void msm_set_quad_tail(bool on);
 void msm_set_split_buckets(bool on);
@@ -1883,6 +1884,12 @@ int h2hip_debug_set_msm_quad_tail(int on) {
 // tuning hook: 1 = order the buckets by size inside each sort bin only (no global pass); 0 = global order (default)
 int h2hip_debug_set_msm_bucket_order(int local) {
     msm_set_bucket_order(local);
+    return 0;
+}
+
+// tuning hook: level-1 records of runs with multi-tile bins as two arrays (1, default) or as (entry, bucket id) pairs (0)
+int h2hip_debug_set_msm_split_records(int on) {
+    msm_set_split_records(on != 0);
     return 0;
 }
 

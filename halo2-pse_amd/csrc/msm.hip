@@ -108,6 +108,8 @@ struct L1Args {
     uint16_t* tile_hist;          // [tiles][C1] entries of the tile per coarse bin (count pass writes, scatter pass reads)
     const uint32_t* tile_off;     // [tiles][C1] where the tile's run of each bin starts in tmp (scatter pass)
     uint2* tmp;                   // (entry, bucket id) grouped by coarse bin
+    uint32_t* tmp_e;              // split records (runs whose bins span several level-2 tiles): the entries ...
+    uint16_t* tmp_k;              // ... and the low L bits of their bucket ids, apart
 };
 
 // PrimeField::to_repr (arithmetic.rs:14) on the unsaturated multiplier: the stored a * 2^256 times 32, divided by the
@@ -196,6 +198,7 @@ __device__ __forceinline__ uint32_t block_scan_base(const uint32_t* cnt, uint32_
 // every bin's share as one contiguous run at the offset A2c computed for (tile, bin).  What bounds this pass is how HBM takes
 // the writes: with 3-entry runs (or a scattered 8-byte store per entry) every run is a partial-line write and the pass ran at
 // 0.6 TB/s; hence at most MSM_MAX_C1 bins for a tile of up to MSM_STAGE entries.
+template <bool SPLIT>
 __global__ void __launch_bounds__(1024) msm_l1_scatter_kernel(L1Args a) {
     __shared__ uint2 stage[MSM_STAGE];
     __shared__ uint32_t cur[MSM_MAX_C1];   // entries per bin, then the bin's cursor in `stage`
@@ -228,7 +231,13 @@ __global__ void __launch_bounds__(1024) msm_l1_scatter_kernel(L1Args a) {
     __syncthreads();
     for (uint32_t pos = threadIdx.x; pos < total; pos += 1024) {
         const uint2 e = stage[pos];
-        a.tmp[pos + delta[e.y >> a.L]] = e;
+        const uint32_t at = pos + delta[e.y >> a.L];
+        if (SPLIT) {
+            a.tmp_e[at] = e.x;
+            a.tmp_k[at] = (uint16_t)(e.y & ((1u << a.L) - 1));
+        } else {
+            a.tmp[at] = e;
+        }
     }
 }
 
@@ -310,7 +319,11 @@ __device__ __forceinline__ uint32_t size_class(uint32_t cnt, uint32_t bin_shift)
 // larger one twice (count, place).  Also writes, for the bin's 2^L buckets: start / counts (empty buckets included) and
 // the accumulate order -- the bin's buckets by descending size class, so that the 64 lanes of an accumulate wave (which
 // takes 64 consecutive entries of perm) get buckets of equal length.
-__global__ void __launch_bounds__(1024) msm_l2_kernel(const uint2* __restrict__ tmp, const uint32_t* __restrict__ coarse_start, uint32_t L,
+// SPLIT: the records come as two arrays (entries, low key bits): a bin of several tiles is read twice -- once for its buckets'
+// sizes, once to place -- and the first read then takes 2 instead of 8 bytes per entry (at 2^24 pairs: 0.4 instead of 1.6 GB).
+template <bool SPLIT>
+__global__ void __launch_bounds__(1024) msm_l2_kernel(const uint2* __restrict__ tmp, const uint32_t* __restrict__ tmp_e, const uint16_t* __restrict__ tmp_k,
+                                                      const uint32_t* __restrict__ coarse_start, uint32_t L,
                                                       uint32_t bin_shift, uint32_t* __restrict__ vals, uint32_t* __restrict__ start,
                                                       uint32_t* __restrict__ counts, uint32_t* __restrict__ perm, uint32_t* __restrict__ class_hist) {
     constexpr uint32_t NBMAX = 1u << MSM_MAX_L, EPT = MSM_STAGE / 1024;
@@ -332,12 +345,12 @@ __global__ void __launch_bounds__(1024) msm_l2_kernel(const uint2* __restrict__ 
         for (uint32_t j = 0; j < EPT; j++) {
             const uint32_t idx = cs + t + j * 1024;
             if (idx < ce) {
-                e[j] = tmp[idx];
+                e[j] = SPLIT ? make_uint2(tmp_e[idx], tmp_k[idx]) : tmp[idx];
                 atomicAdd(&tcur[e[j].y & (nb - 1)], 1u);
             }
         }
     } else {
-        for (uint32_t idx = cs + t; idx < ce; idx += 1024) atomicAdd(&tcur[tmp[idx].y & (nb - 1)], 1u);
+        for (uint32_t idx = cs + t; idx < ce; idx += 1024) atomicAdd(&tcur[(SPLIT ? (uint32_t)tmp_k[idx] : tmp[idx].y) & (nb - 1)], 1u);
     }
     __syncthreads();
     uint32_t total;
@@ -378,7 +391,7 @@ __global__ void __launch_bounds__(1024) msm_l2_kernel(const uint2* __restrict__ 
             for (uint32_t j = 0; j < EPT; j++) {
                 const uint32_t idx = t + j * 1024;
                 if (idx < tile_n) {
-                    e[j] = tmp[base + idx];
+                    e[j] = SPLIT ? make_uint2(tmp_e[base + idx], tmp_k[base + idx]) : tmp[base + idx];
                     atomicAdd(&tcur[e[j].y & (nb - 1)], 1u);
                 }
             }
@@ -870,6 +883,8 @@ __global__ void __launch_bounds__(256) msm_table_step_kernel(const Affine* __res
 static uint32_t g_window_override = 0;
 static size_t g_heavy_div = 32768;
 static size_t g_bin_entries = 8192;
+static bool g_split_records = true;
+void msm_set_split_records(bool on) { g_split_records = on; }
 static uint64_t g_rowcol_lanes = 65536;
 static bool g_rowcol_asm = true, g_rowcol_qtree = true;  // first pass: chains on the explicit-mad multiplier, then the quad tree
 void msm_set_rowcol(uint64_t lanes, uint32_t flavour) {
@@ -1148,11 +1163,22 @@ static int msm_stage_a(Ctx* c, const MsmLayout& L, char* base, const Fe* const* 
     hipLaunchKernelGGL(msm_l1_offsets_kernel, chunks, dim3(256), 0, s, (const uint16_t*)a.tile_hist, L.n_tiles, L.C1, (const uint32_t*)chsum,
                        (const uint32_t*)bin_total, cstart, (uint32_t*)(base + L.o_toff));
     H2_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(msm_l1_scatter_kernel, tiles, dim3(1024), 0, s, a);
+    // bins of several level-2 tiles: split records (see msm_l2_kernel)
+    const bool split = g_split_records && L.E / L.C1 > MSM_STAGE;
+    a.tmp_e = (uint32_t*)(base + L.o_tmp);
+    a.tmp_k = (uint16_t*)(base + L.o_tmp + L.E * 4);
+    if (split)
+        hipLaunchKernelGGL(msm_l1_scatter_kernel<true>, tiles, dim3(1024), 0, s, a);
+    else
+        hipLaunchKernelGGL(msm_l1_scatter_kernel<false>, tiles, dim3(1024), 0, s, a);
     H2_CHECK(hipGetLastError());
     uint32_t* hist = (uint32_t*)(base + L.o_hist);
-    hipLaunchKernelGGL(msm_l2_kernel, dim3(L.C1), dim3(1024), 0, s, (const uint2*)(base + L.o_tmp), cstart, L.L, L.bin_shift, vals, start, counts, perm,
-                       g_global_order ? hist : (uint32_t*)nullptr);
+    if (split)
+        hipLaunchKernelGGL(msm_l2_kernel<true>, dim3(L.C1), dim3(1024), 0, s, (const uint2*)nullptr, (const uint32_t*)a.tmp_e, (const uint16_t*)a.tmp_k, cstart,
+                           L.L, L.bin_shift, vals, start, counts, perm, g_global_order ? hist : (uint32_t*)nullptr);
+    else
+        hipLaunchKernelGGL(msm_l2_kernel<false>, dim3(L.C1), dim3(1024), 0, s, (const uint2*)(base + L.o_tmp), (const uint32_t*)nullptr,
+                           (const uint16_t*)nullptr, cstart, L.L, L.bin_shift, vals, start, counts, perm, g_global_order ? hist : (uint32_t*)nullptr);
     H2_CHECK(hipGetLastError());
     if (g_global_order) {
         hipLaunchKernelGGL(msm_bucket_scatter_kernel, dim3((L.K + 1024 * MSM_BS_PER - 1) / (1024 * MSM_BS_PER)), dim3(1024), 0, s, counts, L.K, L.bin_shift,

@@ -35,6 +35,8 @@ int h2hip_debug_set_msm_split_buckets(int on);
 int h2hip_debug_set_msm_quad_tail(int on);
 /* 1: accumulate order = buckets by size inside each sort bin only; 0 (default): global size order */
 int h2hip_debug_set_msm_bucket_order(int local);
+/* level-1 sort records of runs whose bins span several level-2 tiles: entries and key bits as two arrays (1, default) or 8-byte pairs (0) */
+int h2hip_debug_set_msm_split_records(int on);
 /* target entries per coarse bin of the MSM's two-level sort (default 8192; 0 restores it) */
 int h2hip_debug_set_msm_bin_entries(size_t d);
 /* CUs reserved for the sort / reduce streams of a batched MSM (0 = none: every split measured slower) */

@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--split", type=int, default=1)
     ap.add_argument("--rowcol-lanes", type=int, default=0)
     ap.add_argument("--rowcol-asm", type=int, default=3, help="first row/column pass: bit 0 explicit-mad multiplier, bit 1 quad tree (3 = library default)")
+    ap.add_argument("--split-records", type=int, default=1, help="level-1 sort records as two arrays where bins span several tiles (library default 1)")
     ap.add_argument("--no-stages", action="store_true", help="wall clock only, no per-stage event timers")
     ap.add_argument("--skew", action="store_true", help="prover-like scalars: 90 %% zero, 5 %% in {1, 2}, 5 %% uniform")
     args = ap.parse_args()
@@ -65,6 +66,7 @@ def main():
     import ctypes
     h2.lib().h2hip_debug_set_msm_heavy_div(ctypes.c_size_t(args.heavy_div))
     h2.lib().h2hip_debug_set_msm_bin_entries(ctypes.c_size_t(args.bin_entries))
+    h2.lib().h2hip_debug_set_msm_split_records(ctypes.c_int(args.split_records))
     h2.lib().h2hip_debug_set_msm_bucket_order(ctypes.c_int(args.local_order))
     h2.lib().h2hip_debug_set_msm_quad_tail(ctypes.c_int(args.quad_tail))
     h2.lib().h2hip_debug_set_msm_split_buckets(ctypes.c_int(args.split))
