@@ -648,3 +648,27 @@ def test_msm_batch_fused_equals_pipelined(h2, oracle):
     got = h2.msm_batch_device(cols, dp)
     for j in (0, 3, 12, 13, 14):
         assert np.array_equal(aff(h2, got[j]), aff(h2, h2.msm_device(cols[j], dp))), j
+
+
+def test_alt_bn128_published_known_answer_on_the_gpu(h2, oracle):
+    """EIP-196's ecMul((1, 2), 2) through the engine's MSM (plain and fixed-base form): a known answer published outside this
+    repository (see tests/test_oracle_golden.py::test_alt_bn128_published_known_answers)."""
+    from test_oracle_golden import ALT_BN128_2G, ALT_BN128_Q, ALT_BN128_R, _affine_ints, _g1
+    g = _g1(oracle)
+    n = 1500
+    bs = np.ascontiguousarray(np.repeat(g[None, :], n, axis=0))
+    sc = np.zeros((n, 4), dtype=np.uint64)
+    sc[0] = oracle.fe_from_int(oracle.FR, 2)                      # 2 G + 0 + ...
+    assert _affine_ints(oracle, aff(h2, h2.best_multiexp(sc, bs))) == ALT_BN128_2G
+    sc[:] = oracle.fe_from_int(oracle.FR, 1)
+    sc[7] = oracle.fe_from_int(oracle.FR, ALT_BN128_R - (n - 3))  # the scalars sum to 2 mod r: every bucket path, same answer
+    assert _affine_ints(oracle, aff(h2, h2.best_multiexp(sc, bs))) == ALT_BN128_2G
+    h2.bases_pin(bs)
+    try:
+        assert _affine_ints(oracle, aff(h2, h2.best_multiexp(sc, bs))) == ALT_BN128_2G
+        sc[7] = oracle.fe_from_int(oracle.FR, ALT_BN128_R - (n - 1))  # sum = 0: the identity, encoded (0, 0)
+        assert not aff(h2, h2.best_multiexp(sc, bs)).any()
+        sc[7] = oracle.fe_from_int(oracle.FR, ALT_BN128_R - n)        # sum = -1: -G = (1, q - 2)
+        assert _affine_ints(oracle, aff(h2, h2.best_multiexp(sc, bs))) == (1, ALT_BN128_Q - 2)
+    finally:
+        h2.bases_unpin(bs)

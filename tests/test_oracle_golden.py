@@ -146,3 +146,42 @@ def test_fft_roundtrip_and_linearity(oracle):
     fb = oracle.best_fft(b, d.fe("omega"), k, 1)
     fab = oracle.best_fft(oracle.fe_binop("add", oracle.FR, a, b), d.fe("omega"), k, 4)
     assert np.array_equal(fab, oracle.fe_binop("add", oracle.FR, fa, fb))
+
+
+# ---- published known answers (not minted by this repository) -------------------------------------------------------------------
+# bn256 of halo2curves is alt_bn128, the curve of Ethereum's EIP-196 / EIP-197 precompiles: y^2 = x^3 + 3 over F_q, generator (1, 2),
+# group order r.  The constants below are the ones those EIPs publish (decimal, as printed there); they pin the oracle's moduli,
+# Montgomery conversion and group law to bytes that no script in this repository produced.
+ALT_BN128_Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+ALT_BN128_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+ALT_BN128_2G = (1368015179489954701390400359078579693043519447331113978918064868415326638035,
+                9918110051302171585080402603319702774565515993150576347155970296011118125764)
+
+
+def _affine_ints(oracle, xy):
+    c = oracle.fe_to_canonical(oracle.FQ, np.ascontiguousarray(xy).reshape(2, 4))
+    return oracle.int_from_limbs(c[0]), oracle.int_from_limbs(c[1])
+
+
+def _g1(oracle):
+    return np.concatenate([oracle.fe_from_int(oracle.FQ, 1), oracle.fe_from_int(oracle.FQ, 2)])
+
+
+def test_alt_bn128_published_known_answers(oracle):
+    assert oracle.int_from_limbs(oracle.constant(oracle.FQ, 2)) == ALT_BN128_Q
+    assert oracle.int_from_limbs(oracle.constant(oracle.FR, 2)) == ALT_BN128_R
+    g = _g1(oracle)
+    assert oracle.g1_on_curve(g)
+    two = oracle.fe_from_int(oracle.FR, 2)
+    assert _affine_ints(oracle, oracle.g1_to_affine(oracle.g1_mul(g, two))) == ALT_BN128_2G            # EIP-196 ecMul((1, 2), 2)
+    assert _affine_ints(oracle, oracle.g1_to_affine(oracle.best_multiexp(two[None, :], g[None, :]))) == ALT_BN128_2G
+    # (r - 1) G = -G = (1, q - 2); r G = identity, encoded (0, 0)
+    assert _affine_ints(oracle, oracle.g1_to_affine(oracle.g1_mul(g, oracle.fe_from_int(oracle.FR, ALT_BN128_R - 1)))) == (1, ALT_BN128_Q - 2)
+    gg = np.stack([g, g])
+    sc = np.stack([oracle.fe_from_int(oracle.FR, ALT_BN128_R - 1), oracle.fe_from_int(oracle.FR, 1)])
+    assert not oracle.g1_to_affine(oracle.best_multiexp(sc, gg)).any()
+    # G + G through the addition path, and 2G + 2G = 4G = [4]G
+    dbl = oracle.g1_add(np.concatenate([g, oracle.fe_from_int(oracle.FQ, 1)]), np.concatenate([g, oracle.fe_from_int(oracle.FQ, 1)]))
+    assert _affine_ints(oracle, oracle.g1_to_affine(dbl)) == ALT_BN128_2G
+    four = oracle.g1_to_affine(oracle.g1_mul(g, oracle.fe_from_int(oracle.FR, 4)))
+    assert np.array_equal(oracle.g1_to_affine(oracle.g1_add(dbl, dbl)), four)
