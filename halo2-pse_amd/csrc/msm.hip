@@ -17,22 +17,27 @@
 //                sum IS the result: no Horner.
 //
 // GPU schedule (one stream, no host sync until the set sums come back):
-//   A  msm_l1_kernel<count>    to_repr + get_at (arithmetic.rs:14,24-42): Montgomery -> canonical, signed c-bit
-//                              digits; per-workgroup LDS histogram over coarse bins (bucket id >> L)
-//      msm_l1_scan_kernel      exclusive scan of the coarse-bin sizes
-//      msm_l1_kernel<scatter>  digits again; a workgroup reserves its share of every coarse bin with one atomic
-//                              per bin and writes (entry, bucket id) there
+//   A  msm_l1_count_kernel     to_repr + get_at (arithmetic.rs:14,24-42): Montgomery -> canonical, signed c-bit digits; one
+//                              workgroup per tile of <= 1024 scalars leaves the tile's histogram over the coarse bins
+//                              (bucket id >> L) in HBM -- no global atomics anywhere in level 1
+//      msm_l1_chunk / _scan / _offsets   the [tiles][bins] matrix -> every (tile, bin)'s offset; the scan kernel also clears
+//                              the run's counters
+//      msm_l1_scatter_kernel   digits again; the tile's entries sorted by bin in LDS, every bin's share written as one run of
+//                              (entry, bucket id) records (or entries / key bits apart when bins span several level-2 tiles)
 //      msm_l2_kernel           one workgroup per coarse bin: LDS counting sort on the low L bits -> entries grouped
 //                              by bucket, bucket start / size, size-class histogram
 //      msm_bucket_scatter      buckets ordered by size, so the 64 lanes of a wave get equal-length buckets
-//   B  msm_accum_kernel        one lane per bucket: XYZZ mixed adds over its entries (arithmetic.rs:84-89);
+//   B  msm_accum_kernel        one lane per bucket: XYZZ mixed adds over its entries (arithmetic.rs:84-89); cont = 1: into the
+//                              sums the earlier chunks of a streamed host-slice MSM left there
 //      msm_heavy_*             workgroup-per-chunk accumulation + LDS tree for over-full buckets
-//   C  msm_rowcol_kernel       summation by parts (arithmetic.rs:95-99) restated as plain sums: with the bucket
+//   C  msm_rowcol_*_kernel     summation by parts (arithmetic.rs:95-99) restated as plain sums: with the bucket
 //                              index b = hi * 2^s + lo,  sum (b+1) B_b = 2^s sum hi R_hi + sum (lo+1) C_lo  for the
 //                              row sums R and column sums C; applied twice (first pass: msm_rowcol_qtree_kernel,
 //                              lane chains then a tree of quad-cooperative additions), then
-//      msm_final_kernel        <= 256 small multiples + one tree per bucket set
+//      msm_final_quad_kernel   <= 256 small multiples + trees per bucket set; the last workgroup to arrive sums the partials
+//                              (msm_final_kernel: the lane-per-operation form for runs with many sets)
 //   D  host                    plain form only: Horner over the W set sums with c doublings each
+// Host-resident scalars (the call best_multiexp makes) stream in under stages A and B: msm_stream_host, msm_fused_groups_host.
 #include <hip/hip_ext.h>
 #include <string.h>
 
