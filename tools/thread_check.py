@@ -23,14 +23,14 @@ exp_msm = [h2.g1_to_affine(h2.msm_device(s_, dp_t)) for s_ in ds_t]
 which = sys.argv[2] if len(sys.argv) > 2 else "both"
 bad = []
 def work_ntt(j):
-    for it in range(20):
+    for it in range(int(os.environ.get("ITERS", "20"))):
         c_ = d_big[j].clone()
         h2.ntt_device(c_, dom16.omega, 16)
         torch.cuda.synchronize()
         if not np.array_equal(h2.to_numpy_u64(c_), exp_ntt[j]):
             bad.append(("ntt", j, it))
 def work_msm(j):
-    for it in range(20):
+    for it in range(int(os.environ.get("ITERS", "20"))):
         try:
             r = h2.msm_device(ds_t[j], dp_t)
         except Exception as e:
