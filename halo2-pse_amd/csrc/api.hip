@@ -1636,44 +1636,50 @@ static int batch_args_ok(void* const* d_a, size_t count, uint32_t log_n, const c
 // concurrently (one host thread per device), and the call returns when all of them are done (the caller's stream is
 // synchronised first).  No column crosses xGMI: the caller decides the placement.  With the same device listed twice
 // (HALO2_HIP_ALLOW_DUPLICATE_DEVICES, rehearsal) the columns of that device are dealt round-robin to its contexts.
+// owner[i] = index (in the engine's device list) of the context that transforms column i; *mixed: more than one context is involved.
+// Called with the engine lock held (inside an Entry).
+static int batch_owners(const char* name, void* const* d_a, size_t count, std::vector<int>* owner, bool* mixed) {
+    const int nd = (int)g_devs.size();
+    owner->assign(count, 0);
+    *mixed = false;
+    if (nd <= 1) return 0;
+    std::vector<int> next_dup((size_t)nd, 0);
+    for (size_t i = 0; i < count; i++) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, d_a[i]) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("%s: column %zu is not a device pointer", name, i);
+            return H2HIP_EINVAL;
+        }
+        std::vector<int> cand;
+        for (int d = 0; d < nd; d++)
+            if (g_devs[(size_t)d]->device == at.device) cand.push_back(d);
+        if (cand.empty()) {
+            set_error("%s: column %zu lives on device %d, which is not in h2hip_init's list", name, i, at.device);
+            return H2HIP_EINVAL;
+        }
+        (*owner)[i] = cand[(size_t)(next_dup[(size_t)cand[0]]++) % cand.size()];
+        if ((*owner)[i] != (*owner)[0]) *mixed = true;
+    }
+    return 0;
+}
+
 static int batch_over_devices(const char* name, void* const* d_a, size_t count, void* stream, uint32_t log_n, const Fe& omega, const NttScale* sc) {
     if (!count) return 0;
-    std::vector<int> owner(count, 0);
+    std::vector<int> owner;
     bool mixed = false;
     {
         Entry en(name, d_a[0]);
         if (en.rc) return en.rc;
-        const int nd = (int)g_devs.size();
-        if (nd > 1) {
-            std::vector<int> next_dup((size_t)nd, 0);
-            for (size_t i = 0; i < count; i++) {
-                hipPointerAttribute_t at;
-                if (hipPointerGetAttributes(&at, d_a[i]) != hipSuccess) {
-                    (void)hipGetLastError();
-                    set_error("%s: column %zu is not a device pointer", name, i);
-                    return H2HIP_EINVAL;
-                }
-                std::vector<int> cand;
-                for (int d = 0; d < nd; d++)
-                    if (g_devs[(size_t)d]->device == at.device) cand.push_back(d);
-                if (cand.empty()) {
-                    set_error("%s: column %zu lives on device %d, which is not in h2hip_init's list", name, i, at.device);
-                    return H2HIP_EINVAL;
-                }
-                owner[i] = cand[(size_t)(next_dup[(size_t)cand[0]]++) % cand.size()];
-                if (owner[i] != owner[0]) mixed = true;
-            }
-        }
+        int rc = batch_owners(name, d_a, count, &owner, &mixed);
+        if (rc) return rc;
         if (!mixed) return ntt_device_batch(en.c, (Fe* const*)d_a, nullptr, count, omega, log_n, sc, (hipStream_t)stream);
     }
     Entry en(name, nullptr, true);  // several devices: all their locks, in list order
     if (en.rc) return en.rc;
+    int rc = batch_owners(name, d_a, count, &owner, &mixed);  // again, now that the device list cannot change under the call
+    if (rc) return rc;
     const int nd = (int)g_devs.size();
-    for (size_t i = 0; i < count; i++)
-        if (owner[i] >= nd) {
-            set_error("%s: the engine was re-initialised during the call", name);
-            return H2HIP_EINVAL;
-        }
     H2_CHECK(hipStreamSynchronize((hipStream_t)stream));  // the columns may have been produced on the caller's stream
     std::vector<std::vector<Fe*>> cols((size_t)nd);
     for (size_t i = 0; i < count; i++) cols[(size_t)owner[i]].push_back((Fe*)d_a[i]);
@@ -1681,8 +1687,8 @@ static int batch_over_devices(const char* name, void* const* d_a, size_t count, 
         Ctx* x = g_devs[(size_t)d];
         if (cols[(size_t)d].empty()) return 0;
         H2_CHECK(hipSetDevice(x->device));
-        int rc = ntt_device_batch(x, cols[(size_t)d].data(), nullptr, cols[(size_t)d].size(), omega, log_n, sc, x->stream);
-        if (rc) return rc;
+        int r = ntt_device_batch(x, cols[(size_t)d].data(), nullptr, cols[(size_t)d].size(), omega, log_n, sc, x->stream);
+        if (r) return r;
         H2_CHECK(hipStreamSynchronize(x->stream));
         return 0;
     });
