@@ -175,17 +175,22 @@ def test_fused_batch_groups_split_by_run_capacity(h2, oracle):
         assert np.array_equal(aff(h2, got[j]), want[j]), j
 
 
-@pytest.mark.parametrize("log_n", [20, 22])
+@pytest.mark.parametrize("log_n", [20, 22, 26])
 def test_streamed_msm_full_size_equals_device_resident(h2, log_n):
-    """BASELINE.json configs[1] through the host-pointer entry point with the default chunk ladder: same group element as the
-    device-resident call (which test_msm_full_size_2p20 pins to the oracle), pinned and unpinned"""
+    """BASELINE.json configs[1] -- and the top of the metric range, 2^26 pairs: 2 GiB of scalars in three chunks of up to 34 M
+    pairs -- through the host-pointer entry point with the default chunk ladder: same group element as the device-resident call
+    (which test_msm_full_size_2p20 / test_msm_2p26_quarters_property tie to the oracle), pinned and unpinned"""
     n = 1 << log_n
     ds = h2.gen_scalars_device(0x5EED0001, n)
     dp = h2.gen_points_device(0x5EED0002, n)
     ref = aff(h2, h2.msm_device(ds, dp))
     sc, bs = h2.to_numpy_u64(ds).copy(), h2.to_numpy_u64(dp).copy()
     set_stream(h2, 0)
-    assert np.array_equal(aff(h2, h2.best_multiexp(sc, bs)), ref)
+    if log_n <= 22:  # unpinned: the bases stream in too (at 2^26 that is 4 GiB per call: pinned only)
+        assert np.array_equal(aff(h2, h2.best_multiexp(sc, bs)), ref)
+    del ds, dp
+    import torch
+    torch.cuda.empty_cache()
     h2.bases_pin(bs)
     try:
         assert np.array_equal(aff(h2, h2.best_multiexp(sc, bs)), ref)
@@ -207,3 +212,31 @@ def test_streamed_msm_with_31bit_split(h2, oracle):
         both_forms(h2, sc, bs, want, "split")
     finally:
         h2.lib().h2hip_debug_set_msm_max_chunk(ctypes.c_size_t(0))
+
+
+def test_streamed_msm_degenerate_inputs(h2, oracle):
+    """all-zero scalars (no entry in any chunk), zero scalars in whole chunks only, identity points among the bases, and a size
+    that is not a multiple of anything -- through the default ladder at a size that streams by itself (>= 2^19 pairs)"""
+    n = (1 << 19) + 12345
+    ds = h2.gen_scalars_device(0x5EED0001, n)
+    dp = h2.gen_points_device(0x5EED0002, n)
+    sc, bs = h2.to_numpy_u64(ds).copy(), h2.to_numpy_u64(dp).copy()
+    zero = np.zeros_like(sc)
+    ident = np.zeros(8, dtype=np.uint64)
+    both_forms(h2, zero, bs, ident, "all-zero")
+    tail = zero.copy()
+    tail[-1000:] = sc[-1000:]  # only the last chunk has entries
+    want = aff(h2, h2.msm_device(ds[-1000:], dp[-1000:]))
+    both_forms(h2, tail, bs, want, "last-chunk-only")
+    head = zero.copy()
+    head[:1000] = sc[:1000]    # only the first chunk has entries: later chunks must leave the parts alone
+    want = aff(h2, h2.msm_device(ds[:1000], dp[:1000]))
+    both_forms(h2, head, bs, want, "first-chunk-only")
+    bs2 = bs.copy()
+    bs2[::7] = 0               # identity points (0, 0) among the bases
+    keep = np.ones(n, dtype=bool)
+    keep[::7] = False
+    import torch
+    idx = torch.from_numpy(np.nonzero(keep)[0]).cuda()
+    want = aff(h2, h2.msm_device(ds[idx].contiguous(), dp[idx].contiguous()))
+    both_forms(h2, sc, bs2, want, "identity-bases")
