@@ -240,3 +240,57 @@ def test_streamed_msm_degenerate_inputs(h2, oracle):
     idx = torch.from_numpy(np.nonzero(keep)[0]).cuda()
     want = aff(h2, h2.msm_device(ds[idx].contiguous(), dp[idx].contiguous()))
     both_forms(h2, sc, bs2, want, "identity-bases")
+
+
+def test_host_pointer_entry_points_from_several_threads(h2, oracle):
+    """What a rayon pool does to the drop-in (shplonk/prover.rs:180-196 commits from `par_iter`, permutation/keygen.rs:216-233
+    transforms from several workers): host-pointer MSMs -- streamed, pinned and unpinned -- and host-pointer NTTs entered from
+    four threads at once.  The engine serialises them per device; every result must be the serial one."""
+    import threading
+    n, k = (1 << 16) + 77, 14
+    bs = oracle.gen_points(401, n, num_threads=NT)
+    cols = [oracle.gen_scalars(410 + j, n, num_threads=NT) for j in range(4)]
+    d = h2.EvaluationDomain.new(2, k)
+    polys = [oracle.gen_scalars(420 + j, 1 << k, num_threads=NT) for j in range(4)]
+    set_stream(h2, 3, 600, 4096)
+    h2.bases_pin(bs)
+    try:
+        want_msm = [aff(h2, h2.best_multiexp(c_, bs)) for c_ in cols]
+        want_ntt = []
+        for p_ in polys:
+            a = p_.copy()
+            h2.best_fft(a, d.omega, k)
+            want_ntt.append(a)
+        assert np.array_equal(want_msm[0], oracle.g1_to_affine(oracle.best_multiexp(cols[0], bs, NT)))
+        assert np.array_equal(want_ntt[0], oracle.best_fft(polys[0], d.omega, k, NT))
+        bad = []
+
+        def msm_worker(j):
+            for it in range(6):
+                if not np.array_equal(aff(h2, h2.best_multiexp(cols[j], bs)), want_msm[j]):
+                    bad.append(("msm", j, it))
+
+        def ntt_worker(j):
+            for it in range(6):
+                a = polys[j].copy()
+                h2.best_fft(a, d.omega, k)
+                if not np.array_equal(a, want_ntt[j]):
+                    bad.append(("ntt", j, it))
+
+        def unpinned_worker(j):
+            other = np.ascontiguousarray(bs[::-1])
+            w = oracle.g1_to_affine(oracle.best_multiexp(cols[j], other, 2))
+            for it in range(3):
+                if not np.array_equal(aff(h2, h2.best_multiexp(cols[j], other)), w):
+                    bad.append(("unpinned", j, it))
+
+        ths = [threading.Thread(target=msm_worker, args=(j,)) for j in range(4)]
+        ths += [threading.Thread(target=ntt_worker, args=(j,)) for j in range(4)]
+        ths += [threading.Thread(target=unpinned_worker, args=(0,))]
+        for t_ in ths:
+            t_.start()
+        for t_ in ths:
+            t_.join()
+        assert not bad, bad[:5]
+    finally:
+        h2.bases_unpin(bs)
