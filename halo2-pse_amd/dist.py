@@ -41,3 +41,37 @@ def allgather_fold(partial_xyz, h2, device=None, group=None):
         torch.cuda.current_stream(device).synchronize()
     parts = h_all.numpy().view(np.uint64).reshape(world, 12)
     return h2.g1_fold(parts)
+
+
+def allgather_start(partial_xyz, device=None, group=None, slot=0):
+    """Start the all-gather of this rank's 96-byte partial and return a handle for allgather_finish.  With a device
+    (RCCL) the collective is asynchronous (`async_op=True`): the caller may run the next shard MSM while the bytes
+    travel; two staging slots alternate so that a pending gather's buffers are not overwritten."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    key = (str(device), world, id(group), "async", slot & 1)
+    if key not in _bufs:
+        dev = device if device is not None else "cpu"
+        pin = device is not None
+        _bufs[key] = (torch.empty(12, dtype=torch.int64, device=dev), torch.empty(12 * world, dtype=torch.int64, device=dev),
+                      torch.empty(12, dtype=torch.int64, pin_memory=pin), torch.empty(12 * world, dtype=torch.int64, pin_memory=pin))
+    mine, gathered, h_mine, h_all = _bufs[key]
+    h_mine.numpy()[:] = np.ascontiguousarray(partial_xyz, dtype=np.uint64).view(np.int64)
+    if device is None:
+        work = dist.all_gather_into_tensor(h_all, h_mine, group=group, async_op=True)
+        return (work, None, h_all, world, None)
+    mine.copy_(h_mine, non_blocking=True)
+    work = dist.all_gather_into_tensor(gathered, mine, group=group, async_op=True)
+    return (work, gathered, h_all, world, device)
+
+
+def allgather_finish(handle, h2):
+    """wait for the gather started by allgather_start and fold the partials (arithmetic.rs:153): (12,) uint64"""
+    import torch
+    work, gathered, h_all, world, device = handle
+    work.wait()
+    if device is not None:
+        h_all.copy_(gathered, non_blocking=True)
+        torch.cuda.current_stream(device).synchronize()
+    return h2.g1_fold(h_all.numpy().view(np.uint64).reshape(world, 12))

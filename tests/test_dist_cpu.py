@@ -28,6 +28,11 @@ def _worker(rank, world, port, n, q):
     bs = oracle.gen_points(0x5EED0002, hi - lo, start=lo)
     part = oracle.best_multiexp(sc, bs, 2)
     total = h2dist.allgather_fold(part, h2)
+    # the pipelined form bench.py uses for N > 1: two gathers in flight on alternating staging slots, finished in order
+    h0 = h2dist.allgather_start(part, slot=0)
+    h1 = h2dist.allgather_start(oracle.best_multiexp(sc[:7], bs[:7], 1), slot=1)
+    assert np.array_equal(h2.g1_to_affine(h2dist.allgather_finish(h0, h2)), h2.g1_to_affine(total))
+    h2dist.allgather_finish(h1, h2)
     q.put((rank, h2.g1_to_affine(total).tolist()))
     dist.barrier()
     dist.destroy_process_group()
