@@ -7,7 +7,9 @@ before the timed region (SplitMix64 scalars / try-and-increment points, SURVEY.m
 The bases are pinned the way a ParamsKZG pins g / g_lagrange (h2hip_bases_pin_device: the
 engine's fixed-base window table, built before the timed region; `--form plain` times the
 unpinned form).  With N > 1 ranks each rank runs the same-size shard (weak scaling), the
-96-byte partials are all-gathered over RCCL and folded on every rank (arithmetic.rs:153).
+96-byte partials are all-gathered over RCCL (asynchronously: the gather of step i travels under
+the MSM of step i + 1; all K folds complete inside the timed region) and folded on every rank
+(arithmetic.rs:153).
 `python bench.py --gpus N` started bare spawns the N ranks itself.
 
 Prints ONE JSON line on rank 0.  `value` = bucket-accumulation G1 adds per second over the
@@ -603,7 +605,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "bn254_g1_msm_2p%d_per_gpu" % args.log_n, "pairs_per_gpu": n, "window_bits": c, "windows": W,
                        "signed_digits": True, "form": "fixed-base window table (bases pinned as ParamsKZG pins g / g_lagrange)" if args.form == "fixed"
-                       else "plain (one bucket set per window)", "parallelism": "shard%d+allgather96B" % world},
+                       else "plain (one bucket set per window)", "parallelism": "shard%d+allgather96B%s" % (world, "(async: gather of step i under the MSM of step i+1)" if world > 1 else "")},
             "pairs_per_s": world * n * args.steps / elapsed,
             "stage_ms": stages,
             "pin": pin,
