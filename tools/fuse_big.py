@@ -1,5 +1,5 @@
-import sys, time, ctypes
-sys.path.insert(0, "/root/repo")
+import os, sys, time, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_pkg
 import numpy as np, torch
 h2 = load_pkg(); h2.init(0)

@@ -2,7 +2,7 @@
   * MSM: random sizes (not powers of two) and scalar shapes, plain form, fixed-base form and the CPU oracle agree in affine;
   * NTT: every size 2^1..2^22, both plans and both twiddle sources agree limb for limb, round trips restore the input."""
 import ctypes, os, random, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from __graft_entry__ import load_pkg
 h2 = load_pkg(); h2.init(0)

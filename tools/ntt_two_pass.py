@@ -2,7 +2,7 @@
 without the full inter-pass twiddle table (same limbs; ms per transform).
 KS=18,20,22 picks the sizes."""
 import ctypes, os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_pkg
 h2 = load_pkg(); h2.init(0)
 import torch

@@ -1,7 +1,7 @@
 """ms per call of the transform variants the prover uses, device-resident: plain NTT, iNTT (1/n fused), coeff_to_extended
 (zero-pad + coset scale fused into the first pass), extended_to_coeff (1/n and coset^-1 fused into the last).  KS=20,22 picks sizes."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_pkg
 h2 = load_pkg(); h2.init(0)
 import torch

@@ -1,7 +1,7 @@
 """Entry points from several Python threads at once (per-device locks): python3 tools/thread_check.py [dup|one] [both|ntt|msm]"""
 import os, sys, threading
 import numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import load_pkg
 h2 = load_pkg()
 import torch
