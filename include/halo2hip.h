@@ -5,7 +5,8 @@
  * The reference (eldenpark/halo2-pse, Rust) has no FFI layer: the seam is two generic free
  * functions plus the KZG commit methods built on them.  Each entry point below names the
  * reference interface it replaces (paths relative to halo2_proofs/src/ in the reference);
- * INTEGRATION.md shows the Rust `extern "C"` block and the two-line dispatch patch.
+ * the Rust side ships as files: halo2hip-sys/ (extern block generated from this header, safe wrappers) and
+ * patches/0001..0003 against the reference.
  *
  * Data layout at the boundary (identical to halo2curves 0.3.1 in memory and to
  * SerdeFormat::RawBytes, helpers.rs:13-19):
@@ -19,13 +20,16 @@
  * thread-safe and blocking.  One process drives the GPUs named at h2hip_init: host-pointer MSMs
  * are sharded over all of them inside the call (the fan-out and fold best_multiexp performs over
  * rayon threads, arithmetic.rs:137-153), everything else runs on the first device, or -- for the
- * _device entry points -- on the device that owns the pointers.
+ * _device entry points -- on the device that owns the pointers, under that device's lock only (calls
+ * on different devices overlap; a batched transform whose columns live on several devices is split by owner).
  * There is no CPU fallback inside the library: without a usable GPU every compute entry
  * point fails with H2HIP_EDEVICE.
  *
  * Environment (read at init): HALO2_HIP_DEVICES="0,1,.." device list when h2hip_init gets none;
- * HALO2_HIP_MULTI_GPU_MIN_N (default 2^18) smallest MSM that is sharded; HALO2_HIP_GATHER=rccl|host
- * how the devices' 96-byte partials meet; HALO2_HIP_MSM_WINDOW; HALO2_HIP_FIXED_BASE=0 and
+ * HALO2_HIP_MULTI_GPU_MIN_N (default 2^18) smallest MSM that is sharded; HALO2_HIP_GATHER=host|rccl
+ * how the devices' partial sums meet (default host: each device's sum has come back with its run, the
+ * calling thread folds them; rccl: ncclAllGather from the devices' HBM over xGMI, fixed-base form);
+ * HALO2_HIP_MSM_WINDOW; HALO2_HIP_FIXED_BASE=0 and
  * HALO2_HIP_TABLE_MAX_GB for h2hip_bases_pin's window tables; HALO2_HIP_MSM_MIN_N /
  * HALO2_HIP_NTT_MIN_LOGN thresholds the Rust shim reads back through h2hip_msm_min_n() /
  * h2hip_ntt_min_log_n(); HALO2_HIP_ROCTX=1 roctx ranges around every entry point;
@@ -54,8 +58,8 @@ extern "C" {
 /* Bind the engine to n_devices GPUs (HIP device ordinals).  device_ids == NULL or n_devices == 0: the
  * HALO2_HIP_DEVICES list, else the calling thread's current HIP device.  Idempotent for the same list;
  * a different list needs h2hip_shutdown first (H2HIP_EINVAL otherwise).  With more than one device the
- * engine starts one host thread and one stream per device and, when librccl is present, one RCCL
- * communicator per device (ncclCommInitAll) for the gather of the MSM partials.  An id out of range or
+ * engine starts one host thread and one stream per device and, with HALO2_HIP_GATHER=rccl and librccl
+ * present, one RCCL communicator per device (ncclCommInitAll) for the gather of the MSM partials.  An id out of range or
  * listed twice is H2HIP_EINVAL. */
 int h2hip_init(const int* device_ids, int n_devices);
 void h2hip_shutdown(void);
