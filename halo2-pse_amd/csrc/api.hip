@@ -290,6 +290,11 @@ static void read_config() {
     if (env_u64("HALO2_HIP_LAZY_PIN", &v)) c.lazy_pin_after = (uint32_t)v;
     if (env_u64("HALO2_HIP_NTT_TWIDDLE_MB", &v)) ntt_set_full_twiddle_budget(v << 20);
     if (env_u64("HALO2_HIP_MSM_WINDOW", &v) && v >= 2 && v <= 24) msm_set_window((uint32_t)v);
+    {  // HALO2_HIP_STREAM=0: host-slice MSMs upload whole arrays ahead of the run (no copier thread); HALO2_HIP_STREAM_MIN_N: threshold
+        uint64_t on = 1, min_n = 0;
+        const bool has_on = env_u64("HALO2_HIP_STREAM", &on), has_min = env_u64("HALO2_HIP_STREAM_MIN_N", &min_n);
+        if (has_on || has_min) msm_set_stream(has_on && on == 0 ? 1 : 0, 0.0, has_min ? (size_t)min_n : 0);
+    }
     const char* g = getenv("HALO2_HIP_GATHER");
     if (g && !strcmp(g, "rccl")) c.gather_rccl = true;
     g_cfg = c;

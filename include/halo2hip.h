@@ -29,7 +29,8 @@
  * HALO2_HIP_MULTI_GPU_MIN_N (default 2^18) smallest MSM that is sharded; HALO2_HIP_GATHER=host|rccl
  * how the devices' partial sums meet (default host: each device's sum has come back with its run, the
  * calling thread folds them; rccl: ncclAllGather from the devices' HBM over xGMI, fixed-base form);
- * HALO2_HIP_MSM_WINDOW; HALO2_HIP_FIXED_BASE=0 and
+ * HALO2_HIP_MSM_WINDOW; HALO2_HIP_STREAM=0 uploads a host-slice MSM's arrays whole instead of streaming them in chunks
+ * (no copier thread), HALO2_HIP_STREAM_MIN_N (default 2^19) is the smallest MSM that streams; HALO2_HIP_FIXED_BASE=0 and
  * HALO2_HIP_TABLE_MAX_GB for h2hip_bases_pin's window tables; HALO2_HIP_MSM_MIN_N /
  * HALO2_HIP_NTT_MIN_LOGN thresholds the Rust shim reads back through h2hip_msm_min_n() /
  * h2hip_ntt_min_log_n(); HALO2_HIP_ROCTX=1 roctx ranges around every entry point;

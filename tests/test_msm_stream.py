@@ -294,3 +294,30 @@ def test_host_pointer_entry_points_from_several_threads(h2, oracle):
         assert not bad, bad[:5]
     finally:
         h2.bases_unpin(bs)
+
+
+@pytest.mark.parametrize("env", [{"HALO2_HIP_STREAM": "0"}, {"HALO2_HIP_STREAM_MIN_N": "4096"}])
+def test_streaming_environment_knobs(env):
+    """HALO2_HIP_STREAM=0 (whole uploads, no copier thread) and HALO2_HIP_STREAM_MIN_N (threshold), read at init"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from conftest import load_pkg
+from oracle import oracle
+h2 = load_pkg()
+h2.init()
+n = 30000
+sc = oracle.gen_scalars(7, n, num_threads=8); bs = oracle.gen_points(8, n, num_threads=8)
+want = oracle.g1_to_affine(oracle.best_multiexp(sc, bs, 8))
+ok = np.array_equal(h2.g1_to_affine(h2.best_multiexp(sc, bs)), want)
+h2.bases_pin(bs)
+ok = ok and np.array_equal(h2.g1_to_affine(h2.best_multiexp(sc, bs)), want)
+print("RESULT", ok)
+""" % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1].split()[1] == "True"
