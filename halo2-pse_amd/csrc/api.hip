@@ -25,6 +25,7 @@ int gen_points_device(uint64_t seed, uint64_t start, size_t n, Affine* d_out, hi
 void msm_set_window(uint32_t c);
 void msm_set_max_chunk(size_t m);
 void msm_set_stream(uint32_t chunks, double ratio, size_t min_n);
+size_t msm_debug_ladder(size_t n, uint32_t chunks, double ratio, bool with_bases, size_t* out, size_t cap);
 void msm_set_heavy_div(size_t d);
 void msm_set_bin_entries(size_t d);
 void msm_set_split_records(bool on);
@@ -1854,6 +1855,13 @@ int h2hip_debug_set_msm_max_chunk(size_t m) {
 int h2hip_debug_set_msm_stream(uint32_t chunks, uint32_t ratio_permille, size_t min_n) {
     msm_set_stream(chunks, ratio_permille / 1000.0, min_n);
     return 0;
+}
+
+// test hook, needs no GPU: the chunk sizes a streamed host-slice MSM of n pairs is cut into (chunks / ratio_permille 0 = the
+// defaults in force; with_bases: the points cross PCIe too); returns the number of chunks, sizes[0 .. min(that, cap))
+size_t h2hip_debug_msm_stream_ladder(size_t n, uint32_t chunks, uint32_t ratio_permille, int with_bases, size_t* sizes, size_t cap) {
+    if (!sizes && cap) return 0;
+    return msm_debug_ladder(n, chunks, ratio_permille / 1000.0, with_bases != 0, sizes, cap);
 }
 
 // tuning hook: buckets above (entries of the MSM) / d go to the chunked path (default 32768; 0 restores it)

@@ -1494,10 +1494,12 @@ static int msm_fused_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_h
 // too (unpinned, 96 B per pair) the run is upload-bound: more and nearly equal chunks (6 at 3 x 0.4), 2.55 / 8.3 / 31.3 ms
 // against 3.44 / 13.2 / 51.2 ms.
 static uint32_t g_stream_chunks = 3;
+static bool g_stream_chunks_default = true;  // below 2^20 pairs the default is two chunks; an explicit setting is taken as given
 static double g_stream_ratio = 0.6;
 static size_t g_stream_min_n = (size_t)1 << 19;  // 2^19 pairs: 1.13 -> 1.04 ms (two chunks); 2^18: 0.72 -> 0.80 ms, not worth it
 void msm_set_stream(uint32_t chunks, double ratio, size_t min_n) {
     g_stream_chunks = chunks ? chunks : 3;
+    g_stream_chunks_default = chunks == 0;
     g_stream_ratio = ratio > 0 ? ratio : 0.6;
     g_stream_min_n = min_n ? min_n : ((size_t)1 << 19);
 }
@@ -1630,10 +1632,21 @@ static void stream_ladder(size_t units, uint32_t K, double r, size_t quantum, st
     out->push_back(units - used);
 }
 
+// test hook (host only, no GPU): the chunk sizes a streamed MSM of n pairs would use
+size_t msm_debug_ladder(size_t n, uint32_t chunks, double ratio, bool with_bases, size_t* out, size_t cap) {
+    std::vector<size_t> sz;
+    const uint32_t k0 = chunks ? chunks : g_stream_chunks;
+    const double r = ratio > 0 ? ratio : g_stream_ratio;
+    const uint32_t kk = !chunks && g_stream_chunks_default && n < ((size_t)1 << 20) ? 2 : k0;
+    stream_ladder(n, with_bases ? 2 * kk : kk, with_bases ? 2.0 * r : r, 4096, &sz);
+    for (size_t i = 0; i < sz.size() && i < cap; i++) out[i] = sz[i];
+    return sz.size();
+}
+
 static int msm_stream_host(Ctx* c, const Fe* h_scalars, const Affine* h_bases, const Affine* d_points, const MsmTable* tab, size_t n, XYZZ* h_out,
                            hipStream_t s) {
     std::vector<size_t> sz;
-    const uint32_t kk = n < ((size_t)1 << 20) && g_stream_chunks > 2 ? 2 : g_stream_chunks;
+    const uint32_t kk = g_stream_chunks_default && n < ((size_t)1 << 20) ? 2 : g_stream_chunks;
     stream_ladder(n, h_bases ? 2 * kk : kk, h_bases ? 2.0 * g_stream_ratio : g_stream_ratio, 4096, &sz);
     const size_t K = sz.size();
     MsmLayout Lt;

@@ -16,6 +16,8 @@ extern "C" {
  * sizes grow by 1000 / ratio_permille (default 600 = upload time over compute time per pair); with the bases crossing too
  * (unpinned) twice the chunks at twice the ratio; zeros restore the defaults */
 int h2hip_debug_set_msm_stream(uint32_t chunks, uint32_t ratio_permille, size_t min_n);
+/* needs no GPU: the chunk sizes a streamed MSM of n pairs is cut into (0 = the values in force); returns their number */
+size_t h2hip_debug_msm_stream_ladder(size_t n, uint32_t chunks, uint32_t ratio_permille, int with_bases, size_t* sizes, size_t cap);
 /* split MSM inputs above m pairs into consecutive chunks (default 2^26, the 31-bit pair-index limit; 0 restores it) */
 int h2hip_debug_set_msm_max_chunk(size_t m);
 /* push `count` Jacobian partials per engine device through the library's RCCL all-gather (communicators created on

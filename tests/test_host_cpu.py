@@ -123,3 +123,36 @@ def test_domain_new_matches_the_reference_pinned_pasta_omega(h2):
     assert np.array_equal(h2.BN254_FR.from_int(12345), h2.fr_from_int(12345))
     with pytest.raises(h2.H2HipError):  # the device entry points serve bn256::Fr only
         d.lagrange_to_coeff(np.zeros((32, 4), dtype=np.uint64))
+
+
+def test_stream_chunk_ladder_host_logic(h2):
+    """the chunk ladder of a streamed host-slice MSM (msm.hip stream_ladder; no GPU involved): the pieces cover n exactly, all
+    but the last are multiples of the 4096-scalar count tile, they grow by ~1/ratio for ratio < 1 (every upload ends as the
+    previous chunk's work does) and shrink for ratio > 1 (upload-bound: the last chunk's work is the exposed part), small
+    inputs collapse to fewer pieces, and below 2^20 pairs the default is two"""
+    import ctypes
+    L = h2.lib()
+    L.h2hip_debug_msm_stream_ladder.restype = ctypes.c_size_t
+
+    def ladder(n, chunks=0, permille=0, with_bases=0):
+        out = (ctypes.c_size_t * 32)()
+        k = L.h2hip_debug_msm_stream_ladder(ctypes.c_size_t(n), ctypes.c_uint32(chunks), ctypes.c_uint32(permille), ctypes.c_int(with_bases), out, ctypes.c_size_t(32))
+        return list(out[:k])
+
+    for n in (1 << 20, (1 << 20) + 12345, 1 << 24, (1 << 26) - 1, 600001):
+        for chunks, pm in ((0, 0), (2, 600), (3, 600), (4, 450), (7, 900), (5, 1500)):
+            sz = ladder(n, chunks, pm)
+            assert sum(sz) == n and all(m > 0 for m in sz), (n, chunks, pm, sz)
+            assert all(m % 4096 == 0 for m in sz[:-1])
+            assert len(sz) <= (chunks or 3)
+            if pm and pm < 1000 and len(sz) > 2:
+                assert all(sz[i + 1] > sz[i] for i in range(len(sz) - 2)), sz  # growing (the last takes the remainder)
+            if pm > 1000 and len(sz) > 2:
+                assert all(sz[i + 1] < sz[i] for i in range(len(sz) - 2)), sz
+    assert len(ladder(1 << 20)) == 3 and len(ladder((1 << 20) - 1)) == 2          # defaults: three chunks from 2^20, two below
+    sz = ladder(1 << 20)
+    assert abs(sz[0] / (1 << 20) - 0.184) < 0.01 and abs(sz[2] / (1 << 20) - 0.51) < 0.01   # 1 : 1/0.6 : 1/0.36
+    assert len(ladder(1 << 20, with_bases=1)) == 6                                   # unpinned: twice the chunks at twice the ratio
+    assert ladder(5000, 4, 600) == [5000] and len(ladder(20000, 4, 600)) == 2        # too small to cut that often
+    assert len(ladder(40123, 7, 900)) == 4 and len(ladder(600001, 7, 900)) == 7      # an explicit chunk count is taken as given
+    assert ladder(0, 3, 600) == [0]
