@@ -488,13 +488,6 @@ struct HeavyChunk {
     uint32_t begin, end;
 };
 
-// one bucket-accumulation step: acc += (+/-) points[index], in the unsaturated arithmetic of ecu.cuh
-template <class F>
-__device__ __forceinline__ void accum_signed(XYZZu& acc, const Affine* __restrict__ bases, uint32_t v) {
-    Affine p = bases[v & 0x7fffffffu];
-    xyzzu_add_affine<F>(acc, p, (v >> 31) != 0);
-}
-
 // B: 2^split_log lanes per bucket (one when split_log = 0): lane (bucket, sub) adds the bucket's entries sub, sub + S,
 // sub + 2S, ... into parts[bucket * S + sub].  A run with few buckets (a lone MSM of <= 2^17 pairs over a window table
 // has 2^16) would otherwise be one wave per SIMD walking ~30 dependent additions per lane.
@@ -608,7 +601,24 @@ __device__ __forceinline__ XYZZu block_tree_sum(XYZZu v, XYZZu* sh) {
     return sh[0];
 }
 
-// B-heavy 1: workgroups stride over the chunk list; every wave exits once its index passes the count
+// the same sum with one QUAD of lanes per addition (ecq.cuh): 64 quads, 2 + 1 + ... + 1 = 9 dependent quad additions instead of 8
+// lane additions at twice their latency (an over-full bucket's sum is nothing but such trees: 15 levels for 26 k entries)
+__device__ __forceinline__ XYZZu block_tree_sum_q(const XYZZu& v, XYZZu* sh) {
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    const uint32_t quad = threadIdx.x >> 2, role = threadIdx.x & 3;
+    for (uint32_t stride = 128; stride >= 1; stride >>= 1) {
+        for (uint32_t a = quad; a < stride; a += 64) {
+            const XYZZu x = xyzzu_sum_q(sh[a], sh[a + stride], role);
+            if (role == 0) sh[a] = x;
+        }
+        __syncthreads();
+    }
+    return sh[0];
+}
+
+// B-heavy 1: workgroups stride over the chunk list; every wave exits once its index passes the count.  A lane's entries (four of a
+// 1024-entry chunk) are read up front and the next point is fetched before the current addition.
 __global__ void __launch_bounds__(256) msm_heavy_chunk_kernel(const Affine* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                               const uint32_t* __restrict__ heavy_counts, const HeavyChunk* __restrict__ heavy_chunks,
                                                               XYZZu* __restrict__ chunk_sums) {
@@ -617,8 +627,20 @@ __global__ void __launch_bounds__(256) msm_heavy_chunk_kernel(const Affine* __re
     for (uint32_t ci = blockIdx.x; ci < total; ci += gridDim.x) {
         HeavyChunk ch = heavy_chunks[ci];
         XYZZu acc = xyzzu_identity();
-        for (uint32_t i = ch.begin + threadIdx.x; i < ch.end; i += blockDim.x) accum_signed<FqU>(acc, bases, vals[i]);
-        XYZZu r = block_tree_sum(acc, sh);
+        uint32_t i = ch.begin + threadIdx.x;
+        if (i < ch.end) {
+            uint32_t v = vals[i];
+            Affine p = bases[v & 0x7fffffffu];
+            for (i += blockDim.x; i < ch.end; i += blockDim.x) {
+                const uint32_t vn = vals[i];
+                const Affine pn = bases[vn & 0x7fffffffu];
+                xyzzu_add_affine<FqU>(acc, p, (v >> 31) != 0);
+                v = vn;
+                p = pn;
+            }
+            xyzzu_add_affine<FqU>(acc, p, (v >> 31) != 0);
+        }
+        XYZZu r = block_tree_sum_q(acc, sh);
         if (threadIdx.x == 0) chunk_sums[ci] = r;
         __syncthreads();
     }
@@ -634,7 +656,7 @@ __global__ void __launch_bounds__(256) msm_heavy_final_kernel(const uint32_t* __
         HeavyBucket h = heavy_buckets[hi];
         XYZZu acc = xyzzu_identity();
         for (uint32_t q = threadIdx.x; q < h.n_chunks; q += blockDim.x) xyzzu_add(acc, chunk_sums[h.first_chunk + q]);
-        XYZZu r = block_tree_sum(acc, sh);
+        XYZZu r = block_tree_sum_q(acc, sh);
         if (threadIdx.x == 0) {
             XYZZu* dst = parts + ((size_t)h.bucket << split_log);
             XYZZu cur = *dst;
@@ -1006,7 +1028,7 @@ static MsmPlan make_plan(size_t n, bool fused, const MsmTable* tab, uint32_t for
     const size_t mean = (p.shared ? n * p.W : n) >> p.cb;  // few buckets (narrow windows): the ordinary bucket is not "over-full"
     if (t < 8 * mean) t = 8 * mean;  // the buckets the narrow windows use hold twice the mean
     p.heavy_t = (uint32_t)t;
-    p.chunk = 4096;
+    p.chunk = 1024;  // a heavy bucket's chunk: 256 lanes x 4 entries, then a tree (4096 measured 30-50 us slower on prover-like columns: 16-entry chains)
     return p;
 }
 

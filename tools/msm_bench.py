@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--rowcol-asm", type=int, default=3, help="first row/column pass: bit 0 explicit-mad multiplier, bit 1 quad tree (3 = library default)")
     ap.add_argument("--split-records", type=int, default=1, help="level-1 sort records as two arrays where bins span several tiles (library default 1)")
     ap.add_argument("--no-stages", action="store_true", help="wall clock only, no per-stage event timers")
+    ap.add_argument("--prover-like", action="store_true", help="SURVEY.md 8(d): 90 %% zero, 5 %% in {1, 2}, 5 %% uniform (over-full buckets: the heavy path)")
     ap.add_argument("--skew", action="store_true", help="prover-like scalars: 90 %% zero, 5 %% in {1, 2}, 5 %% uniform")
     args = ap.parse_args()
     h2 = load_pkg()
@@ -79,6 +80,14 @@ def main():
             r = torch.rand(n, device="cuda")
             small = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
             ds = torch.where((r < 0.9)[:, None], small, ds)
+        if args.prover_like:
+            r = torch.rand(n, device="cuda")
+            one = torch.from_numpy(h2.fr_from_int(1).view(np.int64)).cuda()
+            two = torch.from_numpy(h2.fr_from_int(2).view(np.int64)).cuda()
+            ds = ds.view(n, 4).clone()
+            ds[r < 0.9] = 0
+            ds[(r >= 0.9) & (r < 0.925)] = one
+            ds[(r >= 0.925) & (r < 0.95)] = two
         torch.cuda.synchronize()
         ref = None
         for c in args.windows:
