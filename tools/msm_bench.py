@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--split-records", type=int, default=1, help="level-1 sort records as two arrays where bins span several tiles (library default 1)")
     ap.add_argument("--no-stages", action="store_true", help="wall clock only, no per-stage event timers")
     ap.add_argument("--prover-like", action="store_true", help="SURVEY.md 8(d): 90 %% zero, 5 %% in {1, 2}, 5 %% uniform (over-full buckets: the heavy path)")
+    ap.add_argument("--sparse", type=int, default=0, help="all scalars zero but this many (examples/circuit-layout.rs at k = 17: ~26 assigned or blinding rows of 2^17)")
     ap.add_argument("--skew", action="store_true", help="prover-like scalars: 90 %% zero, 5 %% in {1, 2}, 5 %% uniform")
     args = ap.parse_args()
     h2 = load_pkg()
@@ -80,6 +81,10 @@ def main():
             r = torch.rand(n, device="cuda")
             small = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
             ds = torch.where((r < 0.9)[:, None], small, ds)
+        if args.sparse:
+            keep = torch.zeros(n, dtype=torch.bool, device="cuda")
+            keep[torch.randperm(n, device="cuda")[:args.sparse]] = True
+            ds = torch.where(keep[:, None], ds.view(n, 4), torch.zeros_like(ds.view(n, 4)))
         if args.prover_like:
             r = torch.rand(n, device="cuda")
             one = torch.from_numpy(h2.fr_from_int(1).view(np.int64)).cuda()
