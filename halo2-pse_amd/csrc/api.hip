@@ -38,6 +38,8 @@ void msm_set_rowcol(uint64_t lanes, uint32_t flavour);
 void ntt_set_smax(uint32_t v);
 void ntt_set_two_pass(uint32_t lo, uint32_t hi);
 void ntt_set_full_twiddle_budget(uint64_t bytes);
+void ntt_set_batch_bytes(uint64_t bytes);
+void ntt_set_two_pass_log_j(int v);
 void msm_set_reserved_cus(uint32_t k);
 uint32_t msm_get_reserved_cus();
 uint32_t msm_get_window(size_t n);
@@ -1924,6 +1926,12 @@ int h2hip_debug_set_evalh_max_local_slots(uint32_t v) {
     return 0;
 }
 
+// test hook: HBM one group of lookup cosets may take in evaluate_h (0 = default, 2 GB); a small value forces one lookup per group
+int h2hip_debug_set_evalh_lookup_group_bytes(uint64_t v) {
+    evalh_debug_set_lookup_group_bytes(v);
+    return 0;
+}
+
 // test / tuning hook, needs no GPU: compile a graph as evaluate_h would and report the program's size
 int h2hip_debug_evalh_compile_stats(const h2hip_graph* g, uint32_t* n_ops, uint32_t* n_slots) {
     return evalh_debug_compile_stats(g, n_ops, n_slots);
@@ -1944,6 +1952,18 @@ int h2hip_debug_set_ntt_smax(uint32_t v) {
 // tuning hook: HBM (bytes per device) the two-pass plan's full inter-pass twiddle tables may take; 0 = two-level table only
 int h2hip_debug_set_ntt_twiddle_budget(uint64_t bytes) {
     ntt_set_full_twiddle_budget(bytes);
+    return 0;
+}
+
+// tuning hook: bytes of columns + workspace one launch of a batched transform spans (0 = default)
+int h2hip_debug_set_ntt_batch_bytes(uint64_t bytes) {
+    ntt_set_batch_bytes(bytes);
+    return 0;
+}
+
+// tuning hook: log2 columns per workgroup of the two-pass kernels (-1 = default)
+int h2hip_debug_set_ntt_two_pass_log_j(int v) {
+    ntt_set_two_pass_log_j(v);
     return 0;
 }
 

@@ -190,6 +190,7 @@ struct NttScale {
 void ntt_twiddles_free(Ctx* c);
 int ntt_device(Ctx* c, Fe* d_data, const Fe& omega, uint32_t log_n, const NttScale* sc, hipStream_t s, const Fe* d_src = nullptr);
 
+int ntt_power_table(Ctx* c, const Fe& omega, uint32_t log_n, hipStream_t s, const Fu** lo, const Fu** hi, uint32_t* lo_bits);
 int ntt_device_batch(Ctx* c, Fe* const* h_datas, const Fe* const* h_srcs, size_t count, const Fe& omega, uint32_t log_n, const NttScale* sc,
                      hipStream_t s);
 
@@ -204,6 +205,7 @@ int kzg_setup_device(Ctx* c, uint32_t k, const Fe& s, Affine* d_g, Affine* d_gl,
 
 // evalh.hip
 void evalh_debug_set_max_local_slots(uint32_t v);
+void evalh_debug_set_lookup_group_bytes(uint64_t v);
 int evalh_debug_compile_stats(const h2hip_graph* g, uint32_t* n_ops, uint32_t* n_slots);
 int evaluate_h_validate(const h2hip_evalh_desc* d, const void* values);
 int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool dev, hipStream_t s);

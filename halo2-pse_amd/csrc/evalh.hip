@@ -242,7 +242,8 @@ struct PermDev {
     const Fe* const* cosets;  // pk.permutation.cosets
     const Fe *l0, *l_last, *l_active;
     Fu delta, delta_start;    // I-form canonical; delta_start = beta * ZETA (:368)
-    const Fu* omega_pow2;     // [28] extended_omega^(2^j), I-form canonical: extended_omega^idx is a product over the set bits of idx
+    const Fu *pow_lo, *pow_hi;  // the extended domain's two-level power table (the NTT's: omega^i, i < 2^pow_bits; omega^(i << pow_bits)), I-form canonical
+    uint32_t pow_bits;
     uint32_t n_sets, n_cols, chunk_len;
     int32_t last_rotation;
 };
@@ -267,8 +268,8 @@ __global__ void __launch_bounds__(256) evalh_perm_kernel(PermDev p, ColsDev c, F
         v = addn(mul_i(v, c.y), mul_i(subn(ld_i(ld_const_col(p.z, s)[idx]), ld_i(ld_const_col(p.z, s - 1)[r_last])), ld_i(p.l0[idx])));  // [1.1] + [64 * 32 / 169 + 1 = 13.2] = [14.3]
     // (1 - (l_last + l_blind)) * (z_i(wX) prod(p + beta s_j + gamma) - z_i(X) prod(p + delta^j beta X + gamma))   :405-438
     Fu current_delta = p.delta_start;  // beta * ZETA * extended_omega^idx (beta_term, :366-368 and :412)   [1 .. 2]
-    for (uint32_t j = 0; j < c.log_size; j++)
-        if ((idx >> j) & 1) current_delta = mul_i(current_delta, ld_const_fu(p.omega_pow2, j));
+    current_delta = mul_i(current_delta, p.pow_lo[idx & ((1u << p.pow_bits) - 1)]);
+    if (idx >> p.pow_bits) current_delta = mul_i(current_delta, p.pow_hi[idx >> p.pow_bits]);  // uniform over a workgroup
     for (uint32_t s = 0; s < p.n_sets; s++) {
         const uint32_t j0 = s * p.chunk_len, j1 = j0 + p.chunk_len < p.n_cols ? j0 + p.chunk_len : p.n_cols;
         const Fe* zs = ld_const_col(p.z, s);
@@ -595,6 +596,8 @@ static int slot_plan(uint32_t n_slots, size_t size, SlotPlan* out) {
 }
 
 void evalh_debug_set_max_local_slots(uint32_t v) { g_evalh_max_local_slots = v; }
+static size_t g_evalh_lookup_group_bytes = (size_t)2 << 30;  // HBM one group of lookup cosets may take (tests shrink it to force several groups)
+void evalh_debug_set_lookup_group_bytes(uint64_t v) { g_evalh_lookup_group_bytes = v ? (size_t)v : (size_t)2 << 30; }
 
 int evalh_debug_compile_stats(const h2hip_graph* g, uint32_t* n_ops, uint32_t* n_slots) {
     if (!g || !n_ops || !n_slots) {
@@ -706,9 +709,16 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         if (lookup_plans[i].ws_bytes > slots_ws) slots_ws = lookup_plans[i].ws_bytes;
     }
     // ---- device arena: [metadata | columns the engine owns]
-    const size_t n_cols = dev ? (size_t)d->n_advice + d->n_instance + 3
+    // lookup cosets: three buffers per lookup for as many lookups as 2 GB hold (a group); the first group's transforms join the advice /
+    // instance batch, later groups reuse the buffers once the kernels of the group before are queued
+    size_t lk_group = d->n_lookups;
+    if (lk_group) {
+        const size_t fit = g_evalh_lookup_group_bytes / (3 * col_bytes);
+        if (lk_group > fit) lk_group = fit ? fit : 1;
+    }
+    const size_t n_cols = dev ? (size_t)d->n_advice + d->n_instance + 3 * lk_group
                               : (size_t)d->n_fixed + d->n_advice + d->n_instance + 3 /* l0, l_last, l_active */ + d->n_perm_sets + d->n_perm_columns +
-                                    3 /* lookup cosets, reused */ + 1 /* values */;
+                                    3 * lk_group /* lookup cosets, reused per group */ + 1 /* values */;
     size_t meta_cap = 64 * 1024 + prog_bytes(d->custom_gates, gates_prog) + ((size_t)d->n_challenges + 28) * sizeof(Fu) +
                       (8 + 256) * ((size_t)d->n_fixed + d->n_advice + d->n_instance + d->n_perm_sets + 2 * (size_t)d->n_perm_columns + 16);
     for (uint32_t i = 0; i < d->n_lookups; i++) meta_cap += prog_bytes(d->lookup_graphs[i], lookup_progs[i]);
@@ -770,12 +780,21 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
             pcols[j] = kind == H2HIP_ANY_ADVICE ? advice[idx] : kind == H2HIP_ANY_FIXED ? fixed[idx] : instance[idx];  // :404-408
         }
     }
-    Fe* lbuf[3] = {nullptr, nullptr, nullptr};
-    if (d->n_lookups)
-        for (int t = 0; t < 3; t++)
-            if (!(lbuf[t] = (Fe*)ar.take(col_bytes))) bad = true;
+    std::vector<Fe*> lbuf(3 * lk_group, nullptr);
+    for (size_t t = 0; t < lbuf.size(); t++)
+        if (!(lbuf[t] = (Fe*)ar.take(col_bytes))) bad = true;
     for (uint32_t i = 0; i < d->n_lookups; i++)
         if (!d->lookup_product_polys[i] || !d->lookup_permuted_input_polys[i] || !d->lookup_permuted_table_polys[i]) bad = true;
+    auto lookup_poly = [&](uint32_t i, int t) -> const uint64_t* {
+        return t == 0 ? d->lookup_product_polys[i] : t == 1 ? d->lookup_permuted_input_polys[i] : d->lookup_permuted_table_polys[i];
+    };
+    if (!bad)
+        for (size_t i = 0; i < lk_group; i++)  // the first group rides in the main batch
+            for (int t = 0; t < 3; t++) {
+                poly_dst.push_back(lbuf[3 * i + t]);
+                poly_src.push_back(dev ? (const Fe*)lookup_poly((uint32_t)i, t) : nullptr);
+                if (!dev) uploads.push_back({lbuf[3 * i + t], lookup_poly((uint32_t)i, t), n});
+            }
     if (bad) {
         set_error("evaluate_h: null column or arena overflow");
         return 1;
@@ -807,13 +826,7 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         pd.z = mb.put(z.data(), z.size());
         pd.cols = mb.put(pcols.data(), pcols.size());
         pd.cosets = mb.put(pcosets.data(), pcosets.size());
-        Fe pw = ext_omega;
-        Fu pwi[28];
-        for (int j = 0; j < 28; j++) {
-            pwi[j] = to_i(pw);
-            pw = fe_sqr<FrP>(pw);
-        }
-        pd.omega_pow2 = mb.put(pwi, 28);
+        if ((rc = ntt_power_table(c, ext_omega, ek, s, &pd.pow_lo, &pd.pow_hi, &pd.pow_bits))) return rc;
         pd.l0 = l0;
         pd.l_last = l_last;
         pd.l_active = l_active;
@@ -841,7 +854,7 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
     sc.in3[1] = load_fe(d->g_coset);
     sc.in3[2] = load_fe(d->g_coset_inv);
     sc.in_len = n;
-    if ((rc = ntt_device_batch(c, poly_dst.data(), poly_src.data(), n_polys, ext_omega, ek, &sc, s))) return rc;
+    if ((rc = ntt_device_batch(c, poly_dst.data(), poly_src.data(), poly_dst.size(), ext_omega, ek, &sc, s))) return rc;
     const dim3 grid((uint32_t)((size + 255) / 256)), block(256);
 
     // ---- custom gates (:334-360)
@@ -864,17 +877,22 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         H2_CHECK(hipGetLastError());
     }
 
-    // ---- lookups (:443-518): the three cosets of a lookup are formed, used and their buffers reused
+    // ---- lookups (:443-518): the three cosets of a lookup are formed in groups (the first group with the columns above), used, and
+    //      the group's buffers reused
     for (uint32_t i = 0; i < d->n_lookups; i++) {
-        const uint64_t* polys[3] = {d->lookup_product_polys[i], d->lookup_permuted_input_polys[i], d->lookup_permuted_table_polys[i]};
-        const Fe* lsrc[3] = {nullptr, nullptr, nullptr};
-        for (int t = 0; t < 3; t++) {
-            if (dev) lsrc[t] = (const Fe*)polys[t];
-            else H2_CHECK(hipMemcpyAsync(lbuf[t], polys[t], n * sizeof(Fe), hipMemcpyHostToDevice, s));
+        const size_t gi = i % lk_group;
+        if (gi == 0 && i) {  // the next group's cosets
+            const size_t cnt = d->n_lookups - i < lk_group ? d->n_lookups - i : lk_group;
+            std::vector<const Fe*> lsrc(3 * cnt, nullptr);
+            for (size_t q = 0; q < 3 * cnt; q++) {
+                const uint64_t* h = lookup_poly(i + (uint32_t)(q / 3), (int)(q % 3));
+                if (dev) lsrc[q] = (const Fe*)h;
+                else H2_CHECK(hipMemcpyAsync(lbuf[q], h, n * sizeof(Fe), hipMemcpyHostToDevice, s));
+            }
+            if ((rc = ntt_device_batch(c, lbuf.data(), lsrc.data(), 3 * cnt, ext_omega, ek, &sc, s))) return rc;
         }
-        if ((rc = ntt_device_batch(c, lbuf, lsrc, 3, ext_omega, ek, &sc, s))) return rc;
         const ProgDev& lg = lgs[i];
-        LookupDev ld = {lbuf[0], lbuf[1], lbuf[2], l0, l_last, l_active};
+        LookupDev ld = {lbuf[3 * gi], lbuf[3 * gi + 1], lbuf[3 * gi + 2], l0, l_last, l_active};
         const SlotPlan& lp = lookup_plans[i];
         const dim3 g(lp.lanes / 256);
         switch (lp.tier) {

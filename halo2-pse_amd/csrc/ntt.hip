@@ -430,6 +430,10 @@ void ntt_twiddles_free(Ctx* c) {
 
 static uint64_t g_ntt_full_budget = (uint64_t)1 << 30;  // HALO2_HIP_NTT_TWIDDLE_MB: HBM the full inter-pass tables may take per device
 void ntt_set_full_twiddle_budget(uint64_t bytes) { g_ntt_full_budget = bytes; }
+static size_t g_ntt_batch_bytes = (size_t)2 << 30;  // columns + workspace one batched launch may span (ntt_device_batch)
+void ntt_set_batch_bytes(uint64_t bytes) { g_ntt_batch_bytes = bytes ? (size_t)bytes : (size_t)2 << 30; }
+static int g_ntt2_log_j = -1;  // tuning: columns per workgroup of the two-pass kernels (-1 = the plan's choice)
+void ntt_set_two_pass_log_j(int v) { g_ntt2_log_j = v; }
 
 static int get_twiddles(Ctx* c, const Fe& omega, uint32_t log_n, hipStream_t s, TwiddleTable* out) {
     TwiddleKey key;
@@ -455,6 +459,19 @@ static int get_twiddles(Ctx* c, const Fe& omega, uint32_t log_n, hipStream_t s, 
     }
     c->twiddles[key] = t;
     *out = t;
+    return 0;
+}
+
+// omega^e for e < 2^log_n as lo[e & (2^lo_bits - 1)] * hi[e >> lo_bits] (I-form canonical limbs): the domain's cached table, for kernels
+// outside this file (evaluate_h's permutation argument walks extended_omega^row).  Valid until the cache is cleared, which only a
+// transform over a domain not yet in the cache can do.
+int ntt_power_table(Ctx* c, const Fe& omega, uint32_t log_n, hipStream_t s, const Fu** lo, const Fu** hi, uint32_t* lo_bits) {
+    TwiddleTable t;
+    int rc = get_twiddles(c, omega, log_n, s, &t);
+    if (rc) return rc;
+    *lo = t.lo;
+    *hi = t.hi;
+    *lo_bits = t.lo_bits;
     return 0;
 }
 
@@ -694,6 +711,7 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
         p.log_m = log_n;
         if (log_n <= 21 && (rc = get_full_twiddles(c, omega, p, 0, s, &tw))) return rc;
         p.log_j = 1;  // two columns (64-byte rows): four halve the workgroups and measure 6 % slower at 2^22, 24 % at 2^20
+        if (g_ntt2_log_j >= 0 && g_ntt2_log_j <= 3) p.log_j = (uint32_t)g_ntt2_log_j;
         for (int t = 0; t < 2; t++) {
             p.s = S[t];
             p.first = (t == 0);
@@ -770,9 +788,11 @@ int ntt_device_batch(Ctx* c, Fe* const* h_datas, const Fe* const* h_srcs, size_t
         set_error("ntt: log_n=%u exceeds the 2-adicity of Fr (28)", log_n);
         return 1;
     }
-    // A column and its workspace should stay in the 256 MB infinity cache between passes (measured: twelve 2^20 columns
-    // batched at once ran slower than one after the other): batch only as many as fit in about 96 MB.
-    size_t per = ((size_t)96 << 20) / (2 * (sizeof(Fe) << log_n));
+    // One launch per pass for as many columns as 2 GB of columns + workspace hold.  (Until round 3 the cut was 96 MB -- one 2^20 column
+    // per launch -- from a measurement on the three-pass kernels of round 1; with the two-pass kernels a lone 2^20 column is 512
+    // workgroups, two per CU where four fit: eighteen 2^18 -> 2^20 coset NTTs 0.139 -> 0.105 ms each in one launch per pass, ten
+    // 2^17 -> 2^19 0.073 -> 0.062; from 2^22 up it makes no difference: tools/ntt_batch_rate.py.)
+    size_t per = g_ntt_batch_bytes / (2 * (sizeof(Fe) << log_n));
     if (per < 1) per = 1;
     std::vector<const Fe*> firsts(count);
     for (size_t i = 0; i < count; i++) firsts[i] = (h_srcs && h_srcs[i]) ? h_srcs[i] : h_datas[i];

@@ -50,8 +50,14 @@ int h2hip_debug_set_ntt_smax(uint32_t v);
 int h2hip_debug_set_lazy_pin(uint32_t after);
 int h2hip_debug_set_ntt_two_pass(uint32_t lo, uint32_t hi);
 int h2hip_debug_set_ntt_twiddle_budget(uint64_t bytes);
+/* batched transforms: bytes of columns + workspace one launch spans (0 = default) */
+int h2hip_debug_set_ntt_batch_bytes(uint64_t bytes);
+/* two-pass plan: log2 columns per workgroup (-1 = default) */
+int h2hip_debug_set_ntt_two_pass_log_j(int v);
 /* evaluate_h: programs needing more slots than v use the global-workspace form of the kernels (default 256) */
 int h2hip_debug_set_evalh_max_local_slots(uint32_t v);
+/* evaluate_h: HBM one group of lookup cosets may take (0 = default 2 GB; the first group is transformed with the advice columns) */
+int h2hip_debug_set_evalh_lookup_group_bytes(uint64_t v);
 /* evaluate_h: compile a graph as the engine would and report the program's size; needs no GPU */
 int h2hip_debug_evalh_compile_stats(const h2hip_graph* g, uint32_t* n_ops, uint32_t* n_slots);
 

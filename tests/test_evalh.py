@@ -186,10 +186,14 @@ def test_evaluator_new_builds_the_golden_graphs(evalh_golden):
 
 
 @pytest.mark.gpu
-def test_gpu_evaluate_h_device_resident(h2, oracle):
+@pytest.mark.parametrize("group_bytes", [0, 1])
+def test_gpu_evaluate_h_device_resident(h2, oracle, group_bytes):
     """h2hip_evaluate_h_bn254_device: every column already in HBM (torch tensors), values folded in place on the current
-    stream, inputs untouched; equal to the oracle and to the host-pointer entry point"""
+    stream, inputs untouched; equal to the oracle and to the host-pointer entry point.  group_bytes = 1: one lookup per group
+    of coset buffers (the second lookup's cosets are formed after the first lookup's kernel, in the reused buffers) instead of
+    all lookups' cosets in the batch of the advice columns"""
     import torch
+    h2.lib().h2hip_debug_set_evalh_lookup_group_bytes(ctypes.c_uint64(group_bytes))
     case, vin = _random_case(oracle, 11, seed=77)
     h = DescHolder(case)
     want = vin.copy()
@@ -219,11 +223,18 @@ def test_gpu_evaluate_h_device_resident(h2, oracle):
     d.lookup_permuted_table_polys = table([l[2] for l in tens["lookups"]])
     d_values = dev(vin)
     stream = torch.cuda.current_stream().cuda_stream
-    rc = h2.lib().h2hip_evaluate_h_bn254_device(hd.byref(), ctypes.c_void_p(d_values.data_ptr()), ctypes.c_void_p(stream))
-    assert rc == 0, h2.lib().h2hip_last_error()
-    torch.cuda.synchronize()
+    try:
+        rc = h2.lib().h2hip_evaluate_h_bn254_device(hd.byref(), ctypes.c_void_p(d_values.data_ptr()), ctypes.c_void_p(stream))
+        assert rc == 0, h2.lib().h2hip_last_error()
+        torch.cuda.synchronize()
+        got_host = vin.copy()  # the host-pointer entry point under the same grouping
+        rc = h2.lib().h2hip_evaluate_h_bn254(h.byref(), got_host.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0, h2.lib().h2hip_last_error()
+    finally:
+        h2.lib().h2hip_debug_set_evalh_lookup_group_bytes(ctypes.c_uint64(0))
     got = d_values.cpu().numpy().view(np.uint64)
     assert np.array_equal(got, want)
+    assert np.array_equal(got_host, want)
     for key in ("fixed_cosets", "advice_polys", "instance_polys", "perm_product_cosets", "perm_cosets"):
         for t0, t1 in zip(before[key], tens[key]):
             assert torch.equal(t0, t1), key  # inputs are read-only
