@@ -40,6 +40,7 @@ void ntt_set_two_pass(uint32_t lo, uint32_t hi);
 void ntt_set_full_twiddle_budget(uint64_t bytes);
 void ntt_set_batch_bytes(uint64_t bytes);
 void ntt_set_two_pass_log_j(int v);
+void ntt_set_two_pass_batch_wgs(uint64_t v);
 void msm_set_reserved_cus(uint32_t k);
 uint32_t msm_get_reserved_cus();
 uint32_t msm_get_window(size_t n);
@@ -1958,6 +1959,12 @@ int h2hip_debug_set_ntt_twiddle_budget(uint64_t bytes) {
 // tuning hook: bytes of columns + workspace one launch of a batched transform spans (0 = default)
 int h2hip_debug_set_ntt_batch_bytes(uint64_t bytes) {
     ntt_set_batch_bytes(bytes);
+    return 0;
+}
+
+// tuning hook: workgroups per pass from which batched columns of 2^17..2^19 points take the two-pass plan (0 = default 1024)
+int h2hip_debug_set_ntt_two_pass_batch_wgs(uint64_t v) {
+    ntt_set_two_pass_batch_wgs(v);
     return 0;
 }
 

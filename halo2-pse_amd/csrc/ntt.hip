@@ -588,12 +588,17 @@ static uint32_t g_ntt_smax = 8;
 void ntt_set_smax(uint32_t v) { g_ntt_smax = v < 4 ? 4 : (v > 10 ? 10 : v); }
 // Sizes 2^lo..2^hi take the two-pass plan (tiles of 2^10 or 2^11 points, ntt2_*_kernel): measured on MI355X
 // (tools/ntt_two_pass.py) 14 % faster than three passes at 2^20, 9 % at 2^21, 5 % at 2^22; below, too few workgroups.
-static uint32_t g_ntt_two_lo = 20, g_ntt_two_hi = 22;
+// Batched columns of 2^17..2^19 points take it too once the batch brings g_ntt_two_batch_wgs workgroups per pass (a lone 2^19 transform
+// has 256: 0.117 against 0.089 ms; ten of them 0.059 against 0.070 ms each, ten of 2^17 0.018 against 0.022: tools/ntt_batch_rate.py).
+static uint32_t g_ntt_two_lo = 20, g_ntt_two_hi = 22, g_ntt_two_batch_lo = 17;
+static uint64_t g_ntt_two_batch_wgs = 1024;
 static bool g_ntt2_attr[64];
 void ntt_set_two_pass(uint32_t lo, uint32_t hi) {
-    g_ntt_two_lo = lo < 18 ? 18 : lo;
+    g_ntt_two_lo = lo < 16 ? 16 : lo;
     g_ntt_two_hi = hi > 22 ? 22 : hi;
+    g_ntt_two_batch_lo = g_ntt_two_lo < 17 ? g_ntt_two_lo : hi < lo ? 64 : 17;  // hi < lo turns the plan off altogether
 }
+void ntt_set_two_pass_batch_wgs(uint64_t v) { g_ntt_two_batch_wgs = v ? v : 1024; }
 
 // pass radices: one pass up to 2^10, otherwise ceil(log_n / smax) passes of near-equal radix
 static int plan_passes(uint32_t log_n, uint32_t s_out[4]) {
@@ -640,7 +645,8 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
     if (rc0) return rc0;
     WsGuard guard(c, s);
     int tid = c->timer_begin("ntt", s);
-    const bool two = log_n >= g_ntt_two_lo && log_n <= g_ntt_two_hi;
+    const bool two = log_n <= g_ntt_two_hi &&
+                     (log_n >= g_ntt_two_lo || (log_n >= g_ntt_two_batch_lo && ((uint64_t)count << (log_n - (log_n + 1) / 2 - 1)) >= g_ntt_two_batch_wgs));
     uint32_t S[4];
     int P = log_n ? plan_passes(log_n, S) : 1;
     if (two) {

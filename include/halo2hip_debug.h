@@ -52,6 +52,8 @@ int h2hip_debug_set_ntt_two_pass(uint32_t lo, uint32_t hi);
 int h2hip_debug_set_ntt_twiddle_budget(uint64_t bytes);
 /* batched transforms: bytes of columns + workspace one launch spans (0 = default) */
 int h2hip_debug_set_ntt_batch_bytes(uint64_t bytes);
+/* two-pass plan for batched columns of 2^17..2^19 points: from this many workgroups per pass (0 = default 1024) */
+int h2hip_debug_set_ntt_two_pass_batch_wgs(uint64_t v);
 /* two-pass plan: log2 columns per workgroup (-1 = default) */
 int h2hip_debug_set_ntt_two_pass_log_j(int v);
 /* evaluate_h: programs needing more slots than v use the global-workspace form of the kernels (default 256) */

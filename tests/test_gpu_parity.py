@@ -570,14 +570,16 @@ def test_device_resident_column_flow(h2, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", [0, 3, 9, 14, 17, 18])
+@pytest.mark.parametrize("k", [0, 3, 9, 14, 15, 17, 18])
 def test_batched_transforms_equal_single_ones(h2, oracle, k):
     """h2hip_{ntt,ifft,coeff_to_extended}_bn254_fr_batch_device: every column of the batch equals the unbatched entry point
-    (which is checked against the oracle above) -- 1-, 2- and 3-pass sizes, five columns"""
+    (which is checked against the oracle above) -- 1-, 2- and 3-pass sizes, nine columns.  Nine columns of 2^17..2^19 points take
+    the two-pass plan where a lone one takes three passes (k = 15: the coset transform; k = 17: all three), so this also sets
+    the two plans side by side at those sizes."""
     import torch
     d, _ = oracle.domain_new(4, k)
     ek = d.extended_k
-    cols = [h2.gen_scalars_device(4000 + i, 1 << ek) for i in range(5)]
+    cols = [h2.gen_scalars_device(4000 + i, 1 << ek) for i in range(9)]
     torch.cuda.synchronize()
     # NTT over the first 2^k elements of each column
     want = []

@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--batch-mb", type=int, nargs="*", default=[0], help="columns + workspace per batched launch (0 = library default)")
     ap.add_argument("--log-j", type=int, default=-1, help="two-pass plan: log2 columns per workgroup (-1 = default)")
+    ap.add_argument("--two-lo", type=int, default=0, help="smallest log2 size on the two-pass plan (0 = library default)")
+    ap.add_argument("--two-wgs", type=int, default=0, help="workgroups per pass from which batches of 2^17..2^19 take the two-pass plan (0 = default)")
     ap.add_argument("--only", default="", help="comma list of legs: lone,batch,coset")
     args = ap.parse_args()
     import torch
@@ -47,6 +49,9 @@ def main():
     per = {"lone": 1, "batch": args.cols, "coset": args.cols}
     import ctypes
     h2.lib().h2hip_debug_set_ntt_two_pass_log_j(ctypes.c_int(args.log_j))
+    h2.lib().h2hip_debug_set_ntt_two_pass_batch_wgs(ctypes.c_uint64(args.two_wgs))
+    if args.two_lo:
+        h2.lib().h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(args.two_lo), ctypes.c_uint32(22))
     for mb in args.batch_mb:
         h2.lib().h2hip_debug_set_ntt_batch_bytes(ctypes.c_uint64(mb << 20))
         out = {"k": k, "extended_k": ek, "cols": args.cols, "batch_mb": mb}
