@@ -242,7 +242,8 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_final_kernel(NttPass p) {
     for (uint32_t idx = threadIdx.x; idx < (R << p.log_j); idx += NTT_THREADS) {
         uint32_t k = idx >> p.log_j, jj = idx & (J - 1);
         uint64_t oi = ((uint64_t)k << log_nb) + (g << p.log_j) + jj;
-        dst[oi] = fu_mul_canon<FrUA>(x[lds_swz((jj << p.s) + k)], out_const(p, oi));
+        const Fu v = x[lds_swz((jj << p.s) + k)];
+        dst[oi] = p.out_scale ? fu_mul_canon<FrUA>(v, out_const(p, oi)) : fu_canon_fast<FrUA>(v);  // no constant: reduce directly
     }
 }
 
@@ -369,7 +370,7 @@ __global__ void __launch_bounds__(512, 4) ntt2_final_kernel(NttPass p) {
         four([&](uint32_t m) __attribute__((always_inline)) {
             const uint64_t k = threadIdx.x + m * T;
             const uint64_t oi = (k << log_nb) + vb;
-            dst[oi] = fu_mul_canon<FrUA>(y[m], out_const(p, oi));
+            dst[oi] = p.out_scale ? fu_mul_canon<FrUA>(y[m], out_const(p, oi)) : fu_canon_fast<FrUA>(y[m]);  // no constant: reduce directly
         });
     }
 }

@@ -117,6 +117,31 @@ static void test_field(const char* name) {
         v2.l[3] += 5;
         CHECK(!fu_is_zero_mod_p<U>(v2));
     }
+    // fu_canon_fast (the NTT's closing reduction) against fu_canon over its whole contract |value| < 16 p: random loose values,
+    // and every k p + d for k = -15 .. 15 and small d around the quotient boundaries
+    for (int it = 0; it < 200000; it++) {
+        Fu v = fu_slice(rand_fe<P>(0));
+        const int k = (int)(rnd() % 31) - 15;  // value in (-15 p, 16 p)
+        for (int j = 0; j < (k < 0 ? -k : k); j++) v = fu_norm(k < 0 ? fu_sub(v, pf) : fu_add(v, pf));
+        if (it & 1) {  // loose limbs, same value: move 2^29 between neighbours
+            for (int j = 0; j < 8; j++) {
+                const int32_t t = (int32_t)(rnd() % 5) - 2;
+                v.l[j] += t << 29;
+                v.l[j + 1] -= t;
+            }
+        }
+        CHECK(fe_eq(fu_canon_fast<U>(v), fu_canon<U>(v)));
+    }
+    for (int k = -15; k <= 15; k++)
+        for (int dd = -3; dd <= 3; dd++) {
+            Fu v = fu_zero();
+            for (int j = 0; j < (k < 0 ? -k : k); j++) v = fu_norm(k < 0 ? fu_sub(v, pf) : fu_add(v, pf));
+            v.l[0] += dd;
+            CHECK(fe_eq(fu_canon_fast<U>(v), fu_canon<U>(v)));
+            Fu hi = v;  // just below / above the next multiple in the top limbs
+            hi.l[7] += dd * 12345;
+            if (k < 15 && k > -15) CHECK(fe_eq(fu_canon_fast<U>(hi), fu_canon<U>(hi)));
+        }
     printf("%s field fuzz done, failures so far %d\n", name, failures);
 }
 
