@@ -126,7 +126,7 @@ static void test_field(const char* name) {
         if (it & 1) {  // loose limbs, same value: move 2^29 between neighbours
             for (int j = 0; j < 8; j++) {
                 const int32_t t = (int32_t)(rnd() % 5) - 2;
-                v.l[j] += t << 29;
+                v.l[j] += t * (1 << 29);
                 v.l[j + 1] -= t;
             }
         }
