@@ -263,11 +263,20 @@ __host__ __device__ __forceinline__ Fu fu_i_from_fe(const Fe& x) {
 // m = 0, 2, 1, 3, so the first stage pair (or, for odd s, the lone first stage) runs on the loaded values; and the last
 // round's group of half-size R / 4 is exactly {t + m R/4}, so its results never go back to LDS.  In between, the rounds
 // exchange through the image x as dft_lds does.
-__device__ __forceinline__ void dft_col(Fu* x, const Fu* wtab, uint32_t s, const Fu (&v)[4], Fu (&res)[4]) {
+// `quarter` (uniform): rows R / 4 and up are zero (a coefficient vector padded to four times its length, coeff_to_extended's
+// first pass), i.e. v[1] = v[2] = v[3] = 0 in every lane: the first stage pair copies v[0] to its four outputs.
+__device__ __forceinline__ void dft_col(Fu* x, const Fu* wtab, uint32_t s, const Fu (&v)[4], Fu (&res)[4], bool quarter = false) {
     const uint32_t t = threadIdx.x;
     const uint32_t b0 = lds_swz(bitrev(t, s - 2) << 2);  // swz(4 i' + j) = swz(4 i') ^ j
     uint32_t log_h;
-    if (s & 1) {
+    if (!(s & 1) && quarter) {
+        const Fu n0 = fu_norm(v[0]);
+        x[b0] = n0;
+        x[b0 ^ 1] = n0;
+        x[b0 ^ 2] = n0;
+        x[b0 ^ 3] = n0;
+        log_h = 2;
+    } else if (s & 1) {
         x[b0] = fu_norm(fu_add(v[0], v[2]));
         x[b0 ^ 1] = fu_norm(fu_sub(v[0], v[2]));
         x[b0 ^ 2] = fu_norm(fu_add(v[1], v[3]));
@@ -333,6 +342,7 @@ __global__ void __launch_bounds__(512, 4) ntt2_strided_kernel(NttPass p) {
     const uint32_t T = blockDim.x;  // R / 4
     const uint32_t log_l = p.log_n - p.s;
     const uint64_t lo0 = (uint64_t)blockIdx.x << p.log_j;
+    const bool quarter = p.first && (p.in_len << 2) <= (1ull << p.log_n);  // rows T = R / 4 and up lie at T * L = N / 4 and beyond
 #pragma unroll 1
     for (uint32_t c = 0; c < (1u << p.log_j); c++) {
         const uint64_t lo = lo0 + c;
@@ -341,7 +351,7 @@ __global__ void __launch_bounds__(512, 4) ntt2_strided_kernel(NttPass p) {
             const uint64_t r = threadIdx.x + m * T;
             v[m] = ntt_load(p, src, (r << log_l) + lo);
         });
-        dft_col(x, p.stage_tw, p.s, v, y);
+        dft_col(x, p.stage_tw, p.s, v, y, quarter);
         four([&](uint32_t m) __attribute__((always_inline)) {
             const uint64_t k = threadIdx.x + m * T;
             const Fu w = p.tw_full ? p.tw_full[(lo << p.s) + k] : tw_pow(p, k * lo);  // w_N^(k * lo)
