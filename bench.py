@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--prewarm-ms", type=float, default=100.0, help="untimed steps run ahead of the --warmup steps until about this much GPU work has "
+                    "passed: an idle MI355X takes ~50 ms of load to reach its running clocks (3 warm-up steps of 1.25 ms: 1.276 ms per step; 50: 1.245)")
     ap.add_argument("--log-n", type=int, default=20, help="pairs per GPU = 2^log_n")
     ap.add_argument("--ntt-log-n", type=int, default=22)
     ap.add_argument("--window", type=int, default=0, help="MSM window bits (0 = engine default)")
@@ -262,6 +264,10 @@ def main():
     if args.only_ntt:
         args.steps, args.warmup = 1, 0
     result = None
+    # the same count on every rank (the steps hold a collective): from the size, not from a clock
+    prewarm_steps = 0 if args.only_ntt else min(400, int(args.prewarm_ms / (1.25 * 2.0 ** (args.log_n - 20))))
+    for _ in range(prewarm_steps):
+        step()
     for _ in range(args.warmup):
         result = step()
     if world > 1:
@@ -365,7 +371,7 @@ def main():
     def ntt_point(k, reps):
         d = h2.EvaluationDomain.new(2, k)
         d_a = h2.gen_scalars_device(0x5EED0003, 1 << k, device=dev)
-        for _ in range(2):
+        for _ in range(max(2, int(50.0 / 2.0 ** (k - 22)))):  # ~50 ms of untimed transforms: the clocks of an idle chip take that long to come up
             h2.ntt_device(d_a, d.omega, k)
             h2.ifft_device(d_a, d.omega_inv, k, d.ifft_divisor)
         torch.cuda.synchronize()
@@ -474,6 +480,8 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import trace_bench
         sizes["trace_k17"] = trace_bench.run(h2, cpu=False)
+        pl = trace_bench.run(h2, cpu=False, scalars="prover-like")  # SURVEY.md 8(d) config 5's second distribution
+        sizes["trace_k17_prover_like"] = {k_: pl[k_] for k_ in ("scalars", "single_ms", "batched_ms")}
 
     # ---- SURVEY.md 8(f).3 / (f).4 legs (extra keys; rank 0, N = 1 only), outside the MSM timed region ----
     next_rows = None
@@ -597,6 +605,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm_steps": prewarm_steps,
             "ms_per_step": ms_step,
             "higher_is_better": True,
             "scaling": "weak",

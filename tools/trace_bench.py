@@ -14,7 +14,23 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_pkg  # noqa: E402
 
 
-def run(h2, cpu=True, fixed_base=True):
+def prover_like(h2, col, seed):
+    """SURVEY.md 8(d)'s prover-like column: 90 % zero, 5 % in {1, 2}, 5 % uniform (what a sparse advice column looks like in Lagrange form)"""
+    import numpy as np
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    r = torch.rand(col.shape[0], device="cuda", generator=g)
+    one = torch.from_numpy(h2.fr_from_int(1).view(np.int64)).cuda()
+    two = torch.from_numpy(h2.fr_from_int(2).view(np.int64)).cuda()
+    col = col.clone()
+    col[r < 0.9] = 0
+    col[(r >= 0.9) & (r < 0.925)] = one
+    col[(r >= 0.925) & (r < 0.95)] = two
+    return col
+
+
+def run(h2, cpu=True, fixed_base=True, scalars="dense"):
     """returns the result dict; cpu=True also times the oracle on the host cores (imports oracle/: bench/tools only)"""
     import torch
     k = 17
@@ -27,6 +43,9 @@ def run(h2, cpu=True, fixed_base=True):
         h2.bases_pin_device(g)
         h2.bases_pin_device(gl)
     lag = [h2.gen_scalars_device(600 + i, n) for i in range(10)]
+    if scalars == "prover-like":
+        lag = [prover_like(h2, c, 900 + i) for i, c in enumerate(lag)]
+    lag0 = [c.clone() for c in lag]
     ext = [torch.zeros((1 << ek, 4), dtype=torch.int64, device="cuda") for _ in range(10)]
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
@@ -44,7 +63,12 @@ def run(h2, cpu=True, fixed_base=True):
         for e, c in zip(ext, lag):
             e[:n] = c
 
+    def restore():  # the iNTTs below run in place: every repetition starts from the Lagrange-form columns again
+        for c, c0 in zip(lag, lag0):
+            c.copy_(c0)
+
     def single():
+        restore()
         for c in lag:
             h2.msm_device(c, gl)
         for c in lag:
@@ -57,6 +81,7 @@ def run(h2, cpu=True, fixed_base=True):
         h2.extended_to_coeff_device(ext[0], ek, d.extended_omega_inv, d.extended_ifft_divisor, d.g_coset, d.g_coset_inv)
 
     def batched():
+        restore()
         h2.msm_batch_device(lag, gl)
         h2.ifft_batch_device(lag, d.omega_inv, k, d.ifft_divisor)
         h2.msm_batch_device(lag[:6], g)
@@ -64,7 +89,8 @@ def run(h2, cpu=True, fixed_base=True):
         h2.coeff_to_extended_batch_device(ext, k, ek, d.extended_omega, d.g_coset, d.g_coset_inv)
         h2.extended_to_coeff_device(ext[0], ek, d.extended_omega_inv, d.extended_ifft_divisor, d.g_coset, d.g_coset_inv)
 
-    out = {"k": k, "extended_k": ek, "fixed_base": fixed_base, "single_ms": timed(single), "batched_ms": timed(batched), "fill_ext_ms": timed(fill_ext),
+    out = {"k": k, "extended_k": ek, "fixed_base": fixed_base, "scalars": scalars, "single_ms": timed(single), "batched_ms": timed(batched),
+           "fill_ext_ms": timed(fill_ext) + timed(restore),
            "calls": "16 MSMs of 2^17 (10 commit_lagrange + 6 commit), 10 iNTTs, 10 coset NTTs 2^17 -> 2^19, one inverse coset NTT of 2^19"}
     if fixed_base:
         h2.bases_unpin_device(g)
@@ -93,7 +119,8 @@ def run(h2, cpu=True, fixed_base=True):
 def main():
     h2 = load_pkg()
     h2.init()
-    print(json.dumps(run(h2, cpu="--no-cpu" not in sys.argv, fixed_base="--plain" not in sys.argv)))
+    print(json.dumps(run(h2, cpu="--no-cpu" not in sys.argv, fixed_base="--plain" not in sys.argv,
+                         scalars="prover-like" if "--prover-like" in sys.argv else "dense")))
 
 
 if __name__ == "__main__":
