@@ -59,6 +59,12 @@ __device__ __forceinline__ const Fe* ntt_src(const NttPass& p) { return p.srcs ?
 __device__ __forceinline__ Fe* ntt_dst(const NttPass& p) { return p.dsts ? p.dsts[blockIdx.y] : p.dst; }
 
 #define NTT_THREADS 256
+#ifndef NTT2_OWN_FINAL
+#define NTT2_OWN_FINAL 0  // the same in pass 2, whose rows are contiguous: the lanes' 32-byte loads scatter and the pass measures 1 % slower (A/B builds)
+#endif
+#ifndef NTT2_OWN_ROWS
+#define NTT2_OWN_ROWS 1  // two-pass plan, pass 1: a lane loads the rows of its own points (dft_col<true>); 0 = rows t + m R/4 and a workgroup barrier (A/B builds)
+#endif
 
 // Arithmetic: data stays in the reference's E-form (value == a * 2^256 mod r) as lazily reduced
 // 9 x 29-bit limbs (fieldu.cuh); twiddles and scale constants are I-form, so every
@@ -265,9 +271,12 @@ __host__ __device__ __forceinline__ Fu fu_i_from_fe(const Fe& x) {
 // exchange through the image x as dft_lds does.
 // `quarter` (uniform): rows R / 4 and up are zero (a coefficient vector padded to four times its length, coeff_to_extended's
 // first pass), i.e. v[1] = v[2] = v[3] = 0 in every lane: the first stage pair copies v[0] to its four outputs.
+// OWN: the lane brought rows bitrev(t) + m R/4 instead, so its points are 4 t .. 4 t + 3 -- inside the 256 points its own wave works on
+// in the rounds of half-size <= 64 -- and the first stage's results need no workgroup barrier before the next round reads them.
+template <bool OWN = false>
 __device__ __forceinline__ void dft_col(Fu* x, const Fu* wtab, uint32_t s, const Fu (&v)[4], Fu (&res)[4], bool quarter = false) {
     const uint32_t t = threadIdx.x;
-    const uint32_t b0 = lds_swz(bitrev(t, s - 2) << 2);  // swz(4 i' + j) = swz(4 i') ^ j
+    const uint32_t b0 = lds_swz((OWN ? t : bitrev(t, s - 2)) << 2);  // swz(4 i' + j) = swz(4 i') ^ j
     uint32_t log_h;
     if (!(s & 1) && quarter) {
         const Fu n0 = fu_norm(v[0]);
@@ -292,7 +301,8 @@ __device__ __forceinline__ void dft_col(Fu* x, const Fu* wtab, uint32_t s, const
         x[b0 ^ 3] = fu_norm(fu_sub(y1, u3));
         log_h = 2;
     }
-    __syncthreads();
+    if (OWN) round_sync(log_h, true);
+    else __syncthreads();
     for (;; log_h += 2) {
         const bool last = log_h + 2 == s;
         const uint32_t h = 1u << log_h;
@@ -348,10 +358,10 @@ __global__ void __launch_bounds__(512, 4) ntt2_strided_kernel(NttPass p) {
         const uint64_t lo = lo0 + c;
         Fu v[4], y[4];
         four([&](uint32_t m) __attribute__((always_inline)) {
-            const uint64_t r = threadIdx.x + m * T;
+            const uint64_t r = (NTT2_OWN_ROWS ? bitrev(threadIdx.x, p.s - 2) : threadIdx.x) + m * T;  // rows are a stride apart whichever lane takes them: the lane takes those of its own points
             v[m] = ntt_load(p, src, (r << log_l) + lo);
         });
-        dft_col(x, p.stage_tw, p.s, v, y, quarter);
+        dft_col<NTT2_OWN_ROWS>(x, p.stage_tw, p.s, v, y, quarter);
         four([&](uint32_t m) __attribute__((always_inline)) {
             const uint64_t k = threadIdx.x + m * T;
             const Fu w = p.tw_full ? p.tw_full[(lo << p.s) + k] : tw_pow(p, k * lo);  // w_N^(k * lo)
@@ -373,10 +383,10 @@ __global__ void __launch_bounds__(512, 4) ntt2_final_kernel(NttPass p) {
         const uint64_t vb = v0 + c;
         Fu v[4], y[4];
         four([&](uint32_t m) __attribute__((always_inline)) {
-            const uint64_t r = threadIdx.x + m * T;
+            const uint64_t r = (NTT2_OWN_FINAL ? bitrev(threadIdx.x, p.s - 2) : threadIdx.x) + m * T;
             v[m] = fu_slice(src[(vb << p.s) + r]);
         });
-        dft_col(x, p.stage_tw, p.s, v, y);
+        dft_col<NTT2_OWN_FINAL>(x, p.stage_tw, p.s, v, y);
         four([&](uint32_t m) __attribute__((always_inline)) {
             const uint64_t k = threadIdx.x + m * T;
             const uint64_t oi = (k << log_nb) + vb;
