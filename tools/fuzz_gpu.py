@@ -55,7 +55,7 @@ for k in range(1, 23):
     d = h2.EvaluationDomain.new(2, k)
     a = h2.gen_scalars_device(40 + k, 1 << k)
     outs = []
-    for lo, hi, budget in ((1, 0, 1 << 30), (18, 22, 1 << 30), (1, 0, 0), (18, 22, 0)):
+    for lo, hi, budget in ((1, 0, 1 << 30), (16, 22, 1 << 30), (1, 0, 0), (16, 22, 0)):
         L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(lo), ctypes.c_uint32(hi))
         L.h2hip_debug_set_ntt_twiddle_budget(ctypes.c_uint64(budget))
         x = a.clone(); h2.ntt_device(x, d.omega, k)
@@ -69,5 +69,33 @@ for k in range(1, 23):
         ok = ok and np.array_equal(h2.to_numpy_u64(outs[0][0]), oracle.best_fft(h2.to_numpy_u64(a).copy(), d.omega, k, NT))
     bad += not ok
     print("ntt 2^%d %s" % (k, "ok" if ok else "MISMATCH"), flush=True)
+# round 3: batched zero-padded coset transforms (coeff_to_extended) -- padding ratios 2, 4, 8, random column counts, the two-pass plan
+# forced from 2^16 points and one workgroup up (first stage pair skipped at ratio >= 4, rows taken by the lanes of their own points)
+# against one column at a time on the three-pass plan
+for it in range(int(os.environ.get("COSET_CASES", "24"))):
+    k = rng.randrange(8, 19)
+    rlog = rng.choice([1, 2, 2, 3])
+    ek = min(k + rlog, 21)
+    rlog = ek - k
+    cnt = rng.randrange(1, 13)
+    d = h2.EvaluationDomain.new(2 ** rlog + 1, k)
+    assert d.extended_k == ek, (d.extended_k, ek)
+    cols = [h2.gen_scalars_device(5000 + 16 * it + j, 1 << ek) for j in range(cnt)]
+    L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(1), ctypes.c_uint32(0))
+    want = [c.clone() for c in cols]
+    for w in want:
+        h2.coeff_to_extended_device(w, k, ek, d.extended_omega, d.g_coset, d.g_coset_inv)
+    L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(16), ctypes.c_uint32(22))
+    L.h2hip_debug_set_ntt_two_pass_batch_wgs(ctypes.c_uint64(1))
+    got = [c.clone() for c in cols]
+    h2.coeff_to_extended_batch_device(got, k, ek, d.extended_omega, d.g_coset, d.g_coset_inv)
+    L.h2hip_debug_set_ntt_two_pass_batch_wgs(ctypes.c_uint64(0))
+    L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(20), ctypes.c_uint32(22))
+    got2 = [c.clone() for c in cols]
+    h2.coeff_to_extended_batch_device(got2, k, ek, d.extended_omega, d.g_coset, d.g_coset_inv)  # the library's own choice of plan
+    torch.cuda.synchronize()
+    ok = all(torch.equal(g_, w) and torch.equal(g2, w) for g_, g2, w in zip(got, got2, want))
+    bad += not ok
+    print("coset 2^%d -> 2^%d x %d %s" % (k, ek, cnt, "ok" if ok else "MISMATCH"), flush=True)
 print("FAILURES", bad)
 sys.exit(1 if bad else 0)
