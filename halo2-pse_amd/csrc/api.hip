@@ -750,19 +750,11 @@ static bool pinned_validate(const uint64_t* bases_xy, size_t n) {
 // ---- device-pointer keys (h2hip_bases_pin_device) ---------------------------------------------------------------------------
 // The key is a device address; torch's caching allocator hands the same address out again readily, so a caller that freed a
 // pinned buffer without unpinning it would get the OLD table's commitments.  Guard: the entry keeps H2_PIN_SAMPLES points of
-// the array in device memory; a one-wave kernel queued ahead of the MSM compares them with the caller's buffer and writes its
+// the array in device memory; the first workgroup of the MSM's first kernel (msm_l1_count_kernel) compares them with the caller's buffer and writes its
 // verdict to a pinned host word, which is read when the MSM's own result has arrived (the call waits for that anyway: no extra
 // synchronisation).  A mismatch drops the entry and the MSM is run again in the plain form over the caller's points.
 __global__ void pin_sample_kernel(const Affine* __restrict__ src, size_t total, Affine* __restrict__ out) {
     if (threadIdx.x < H2_PIN_SAMPLES) out[threadIdx.x] = src[pin_sample_index(total, threadIdx.x)];
-}
-
-__global__ void pin_check_kernel(const Affine* __restrict__ bases, size_t n, size_t total, const Affine* __restrict__ samples, uint32_t* flag) {
-    const uint32_t k = threadIdx.x >> 2, part = threadIdx.x & 3;  // 16 points x 4 pieces of 16 B
-    const size_t idx = pin_sample_index(total, k);
-    if (idx >= n) return;
-    const uint4 a = reinterpret_cast<const uint4*>(&bases[idx])[part], b = reinterpret_cast<const uint4*>(&samples[k])[part];
-    if (a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w) atomicOr(flag, 1u);
 }
 
 // window table of a device-pointer key on context c, if n fits; *entry gets the cache entry
@@ -790,10 +782,14 @@ static int msm_device_keyed(Ctx* c, const Fe* const* d_scalars, const Affine* d_
         if (rc) return rc;
         flag = (volatile uint32_t*)c->pin_flag.p;
         *flag = 0;
-        hipLaunchKernelGGL(pin_check_kernel, dim3(1), dim3(64), 0, s, d_bases, n, pb->n, (const Affine*)pb->d_sample, (uint32_t*)c->pin_flag.p);
-        H2_CHECK(hipGetLastError());
+        c->pin_chk.bases = d_bases;
+        c->pin_chk.samples = (const Affine*)pb->d_sample;
+        c->pin_chk.flag = (uint32_t*)c->pin_flag.p;
+        c->pin_chk.n = n;
+        c->pin_chk.total = pb->n;
     }
     int rc = msm_batch_device(c, d_scalars, false, d_bases, n, count, out, s, t);
+    c->pin_chk = Ctx::PinCheck();
     if (rc || !flag || !*flag) return rc;
     // stale: another array lives at the pinned address now
     H2_CHECK(hipDeviceSynchronize());

@@ -85,8 +85,8 @@ struct PinnedBases {
     // fingerprint of the caller's array at pin time: H2_PIN_SAMPLES points (pin_sample_index: the first one and a geometric
     // ladder up to the last, so that every prefix length still sees several), compared byte for byte on every lookup -- a
     // freed-and-reused allocation at the same address must not hit the stale copy.  Host keys: compared on the host
-    // (pinned_validate); device keys: d_sample holds the same bytes in device memory and a one-wave kernel ahead of the MSM
-    // compares them with the caller's buffer (pin_check_kernel), its verdict is read when the MSM's own result arrives.
+    // (pinned_validate); device keys: d_sample holds the same bytes in device memory and the first workgroup of the MSM's first
+    // kernel compares them with the caller's buffer (Ctx::pin_chk -> msm_l1_count_kernel), its verdict is read when the MSM's own result arrives.
     uint8_t sample[H2_PIN_SAMPLES * 64];
     void* d_sample = nullptr;
     size_t lo = 0, hi = 0;     // multi-GPU: this device holds points [lo, hi) of the caller's array (n = hi - lo)
@@ -110,6 +110,14 @@ struct Ctx {
     DevBuf ntt_ws, ntt_io, msm_scalars[3], msm_bases, msm_slot[3], misc, evalh_ws, evalh_slots, ecfft_ws, ntt_ptrs, gather, gen_table;
     HostBuf host_ws;               // pinned host memory for the window sums coming back
     HostBuf pin_flag;              // one word the device-key fingerprint check writes its verdict to
+    // a fingerprint check the next MSM run's first kernel carries out (msm_l1_count_kernel's first workgroup: no launch of its own);
+    // set by msm_device_keyed around its msm_batch_device call, taken by the first msm_stage_a
+    struct PinCheck {
+        const Affine* bases = nullptr;
+        const Affine* samples = nullptr;
+        uint32_t* flag = nullptr;
+        size_t n = 0, total = 0;
+    } pin_chk;
     // Small host tables the kernels read (pointer lists, constants) go through this pinned ring, so that the
     // asynchronous copy never reads a caller's stack or a std::vector that is gone by the time the DMA runs.
     HostBuf stage;

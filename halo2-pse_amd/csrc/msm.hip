@@ -115,6 +115,11 @@ struct L1Args {
     uint2* tmp;                   // (entry, bucket id) grouped by coarse bin
     uint32_t* tmp_e;              // split records (runs whose bins span several level-2 tiles): the entries ...
     uint16_t* tmp_k;              // ... and the low L bits of their bucket ids, apart
+    // device-key pin guard (api.hip msm_device_keyed): the count pass's first workgroup compares the sampled points
+    const Affine* chk_bases;
+    const Affine* chk_samples;
+    uint32_t* chk_flag;           // null: no check
+    size_t chk_n, chk_total;
 };
 
 // PrimeField::to_repr (arithmetic.rs:14) on the unsaturated multiplier: the stored a * 2^256 times 32, divided by the
@@ -137,6 +142,14 @@ __device__ __forceinline__ Fe fr_to_canonical(const Fe& x) {
 // A1: histogram of the tile over the coarse bins
 __global__ void __launch_bounds__(256) msm_l1_count_kernel(L1Args a) {
     __shared__ uint32_t lh[MSM_MAX_C1];
+    if (a.chk_flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4 * H2_PIN_SAMPLES) {  // 16 points x 4 pieces of 16 B
+        const uint32_t k = threadIdx.x >> 2, part = threadIdx.x & 3;
+        const size_t idx = pin_sample_index(a.chk_total, k);
+        if (idx < a.chk_n) {
+            const uint4 u = reinterpret_cast<const uint4*>(&a.chk_bases[idx])[part], v = reinterpret_cast<const uint4*>(&a.chk_samples[k])[part];
+            if (u.x != v.x || u.y != v.y || u.z != v.z || u.w != v.w) atomicOr(a.chk_flag, 1u);
+        }
+    }
     for (uint32_t b = threadIdx.x; b < a.C1; b += 256) lh[b] = 0;
     __syncthreads();
     const Fe* __restrict__ scalars = a.list ? a.list[blockIdx.y] : a.scalars_one;
@@ -1205,6 +1218,12 @@ static int msm_stage_a(Ctx* c, const MsmLayout& L, char* base, const Fe* const* 
     a.tile_hist = (uint16_t*)(base + L.o_thist);
     a.tile_off = (const uint32_t*)(base + L.o_toff);
     a.tmp = (uint2*)(base + L.o_tmp);
+    a.chk_bases = c->pin_chk.bases;
+    a.chk_samples = c->pin_chk.samples;
+    a.chk_flag = c->pin_chk.flag;
+    a.chk_n = c->pin_chk.n;
+    a.chk_total = c->pin_chk.total;
+    c->pin_chk = Ctx::PinCheck();  // once per call
     uint32_t* chsum = (uint32_t*)(base + L.o_chsum);
     const dim3 tiles(L.tiles_x, L.fuse), chunks(L.n_tchunks, (L.C1 + 255) / 256);
     hipLaunchKernelGGL(msm_l1_count_kernel, tiles, dim3(256), 0, s, a);
@@ -1325,7 +1344,10 @@ static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_sums, hip
     XYZZu* buckets = (XYZZu*)(base + L.o_buckets);
     XYZZu *RA = (XYZZu*)(base + L.o_RA), *CA = (XYZZu*)(base + L.o_CA), *RR = (XYZZu*)(base + L.o_RR), *RC = (XYZZu*)(base + L.o_RC);
     XYZZu *CR = (XYZZu*)(base + L.o_CR), *CC = (XYZZu*)(base + L.o_CC);
-    XYZZ* sums = (XYZZ*)(base + L.o_sums);
+    // The sums go straight into the caller's pinned host buffer (a HostBuf: device-visible, as pin_flag is) -- no copy launch
+    // behind the last kernel; a multi-device run that gathers over RCCL keeps them in HBM and copies (api.hip gather_rccl).
+    const bool direct = !c->gather_want;
+    XYZZ* sums = direct ? h_sums : (XYZZ*)(base + L.o_sums);
     const uint32_t ns = L.n_sets, cb = L.p.cb;
     // few sets: the second row/column pass and the final scaling are latency chains on a handful of waves -- one quad of
     // lanes per group operation (ecq.cuh).  Many sets (fused batches of the plain form) fill the chip: one lane each.
@@ -1388,7 +1410,7 @@ static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_sums, hip
     }
     H2_CHECK(hipGetLastError());
     c->timer_end(t4, s);
-    H2_CHECK(hipMemcpyAsync(h_sums, sums, (size_t)ns * sizeof(XYZZ), hipMemcpyDeviceToHost, s));
+    if (!direct) H2_CHECK(hipMemcpyAsync(h_sums, sums, (size_t)ns * sizeof(XYZZ), hipMemcpyDeviceToHost, s));
     if (c->gather_want) {  // the same sums stay on the device for the RCCL gather of a multi-device MSM (api.hip gather_rccl)
         const size_t bytes = (size_t)ns * sizeof(XYZZ);
         if (c->gather_off + bytes <= H2_GATHER_OWN && c->gather.p)
