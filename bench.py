@@ -43,7 +43,7 @@ MSM_BYTES_PER_PAIR = 96  # 32 B scalar + 64 B affine point, read once (SURVEY.md
 NTT_BYTES_PER_ELEM = 64  # one 32 B read + one 32 B write per transform
 FIELD_MUL_PER_BUCKET_ADD = 9.2  # XYZZ mixed add: 7 products + 2 squares + one two-product single-reduction form (csrc/ecu.cuh)
 FIELD_MUL_PEAK_G = 179.0  # measured peak of csrc/fieldu.cuh's multiplier on MI355X, G multiplies/s (tools/mul_rate.hip)
-STAGES = ("msm_total", "msm_digits", "msm_sort", "msm_accum", "msm_heavy", "msm_reduce")
+STAGES = ("msm_total", "msm_digits", "msm_sort", "msm_accum", "msm_reduce")  # over-full buckets are summed inside the accumulate launch
 
 
 def cpu_model():

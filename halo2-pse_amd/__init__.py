@@ -17,7 +17,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhalo2hip.so")
+LIB_PATH = os.environ.get("HALO2_HIP_LIB") or os.path.join(_HERE, "libhalo2hip.so")  # HALO2_HIP_LIB: another build of the library (A/B measurements)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "halo2hip.h")
 
 _lib = None

@@ -466,10 +466,38 @@ __global__ void __launch_bounds__(1024) msm_l2_kernel(const uint2* __restrict__ 
 // returning atomic per (workgroup, class) on 256 addresses -- with 256-bucket workgroups those atomics, serialised per
 // address, were the whole 31 us of this kernel at 2^19 buckets.
 #define MSM_BS_PER 4u
-__global__ void __launch_bounds__(1024) msm_bucket_scatter_kernel(const uint32_t* __restrict__ counts, uint32_t n_buckets, uint32_t bin_shift,
-                                                                  uint32_t* __restrict__ hist, uint32_t* __restrict__ perm) {
+// Over-full buckets (more than heavy_t entries: the zeros, ones and twos of a prover's column) are summed chunk by chunk by
+// workgroups of their own (msm_accum_kernel's first `hgrid` workgroups).  The list of those buckets and of their chunks is made
+// here, where every bucket's size passes by anyway; `arrived` counts a bucket's finished chunks.
+struct HeavyBucket {
+    uint32_t bucket, first_chunk, n_chunks, arrived;
+};
+struct HeavyChunk {
+    uint32_t begin, end, owner;  // entries [begin, end) of heavy bucket number `owner`
+};
+
+__global__ void __launch_bounds__(1024) msm_bucket_scatter_kernel(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ start, uint32_t n_buckets,
+                                                                  uint32_t bin_shift, uint32_t heavy_t, uint32_t chunk, uint32_t* __restrict__ hist,
+                                                                  uint32_t* __restrict__ perm, uint32_t* __restrict__ heavy_counts,
+                                                                  HeavyBucket* __restrict__ heavy_buckets, HeavyChunk* __restrict__ heavy_chunks) {
     __shared__ uint32_t scan[256], lh[256], lbase[256], ps[16];
     const uint32_t t = threadIdx.x;
+    for (uint32_t j = 0; j < MSM_BS_PER; j++) {
+        const uint32_t b = (blockIdx.x * 1024 + t) * MSM_BS_PER + j;
+        const uint32_t cnt = b < n_buckets ? counts[b] : 0;
+        if (cnt > heavy_t) {
+            const uint32_t s0 = start[b], e0 = s0 + cnt, nch = (cnt + chunk - 1) / chunk;
+            const uint32_t slot = atomicAdd(&heavy_counts[1], nch);
+            const uint32_t hb = atomicAdd(&heavy_counts[0], 1u);
+            const HeavyBucket h = {b, slot, nch, 0};
+            heavy_buckets[hb] = h;
+            for (uint32_t q = 0; q < nch; q++) {
+                const HeavyChunk ch = {s0 + q * chunk, (s0 + (q + 1) * chunk < e0) ? s0 + (q + 1) * chunk : e0, hb};
+                heavy_chunks[slot + q] = ch;
+            }
+        }
+    }
+    if (!perm) return;  // bucket order local to the sort bins (debug knob): only the list above
     if (t < 256) lh[t] = 0;
     uint32_t total;
     const uint32_t excl = block_scan_base<1024>(hist, 256, 1, ps, &total);  // exclusive scan of the class counts (every block repeats it)
@@ -494,23 +522,29 @@ __global__ void __launch_bounds__(1024) msm_bucket_scatter_kernel(const uint32_t
         if (b0 + j < n_buckets) perm[scan[cls[j]] + lbase[cls[j]] + rank[j]] = b0 + j;
 }
 
-struct HeavyBucket {
-    uint32_t bucket, first_chunk, n_chunks, pad;
-};
-struct HeavyChunk {
-    uint32_t begin, end;
-};
+// the heavy role of msm_accum_kernel (defined below, after the tree sums it uses)
+__device__ __noinline__ void msm_heavy_role(const Affine* __restrict__ bases, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ heavy_counts,
+                                            HeavyBucket* __restrict__ heavy_buckets, const HeavyChunk* __restrict__ heavy_chunks,
+                                            XYZZu* __restrict__ chunk_sums, uint32_t split_log, uint32_t cont, XYZZu* __restrict__ parts, uint32_t hgrid,
+                                            XYZZu* sh);
 
 // B: 2^split_log lanes per bucket (one when split_log = 0): lane (bucket, sub) adds the bucket's entries sub, sub + S,
 // sub + 2S, ... into parts[bucket * S + sub].  A run with few buckets (a lone MSM of <= 2^17 pairs over a window table
 // has 2^16) would otherwise be one wave per SIMD walking ~30 dependent additions per lane.
 // `bases` is the caller's point array (plain form) or the window table (fixed-base form).
-__global__ void __launch_bounds__(256) msm_accum_kernel(const Affine* __restrict__ bases, const uint32_t* __restrict__ vals,
+__global__ void __launch_bounds__(256, 4) msm_accum_kernel(const Affine* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                         const uint32_t* __restrict__ start, const uint32_t* __restrict__ counts,
                                                         const uint32_t* __restrict__ perm, uint32_t n_buckets, uint32_t split_log, uint32_t heavy_t,
-                                                        uint32_t chunk, uint32_t cont, XYZZu* __restrict__ parts, uint32_t* __restrict__ heavy_counts,
-                                                        HeavyBucket* __restrict__ heavy_buckets, HeavyChunk* __restrict__ heavy_chunks) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+                                                        uint32_t cont, XYZZu* __restrict__ parts, uint32_t hgrid, const uint32_t* __restrict__ heavy_counts,
+                                                        HeavyBucket* __restrict__ heavy_buckets, const HeavyChunk* __restrict__ heavy_chunks,
+                                                        XYZZu* __restrict__ chunk_sums) {
+    // one LDS block for both roles: the heavy role's 256 sums (27 KB) or the accumulate role's point buffer (16 KB); four workgroups per CU
+    __shared__ __align__(16) unsigned char lds_raw[256 * sizeof(XYZZu)];
+    if (blockIdx.x < hgrid) {
+        msm_heavy_role(bases, vals, heavy_counts, heavy_buckets, heavy_chunks, chunk_sums, split_log, cont, parts, hgrid, reinterpret_cast<XYZZu*>(lds_raw));
+        return;
+    }
+    uint32_t t = (blockIdx.x - hgrid) * blockDim.x + threadIdx.x;
     if ((t >> split_log) >= n_buckets) return;
     const uint32_t S = 1u << split_log, sub = t & (S - 1);
     const uint32_t b = perm[t >> split_log];  // buckets in descending size order
@@ -519,23 +553,14 @@ __global__ void __launch_bounds__(256) msm_accum_kernel(const Affine* __restrict
     XYZZu* const mine = parts + (((size_t)b << split_log) + sub);
     bool store = !cont;  // cont: the parts hold the sums of the earlier chunks of a streamed MSM; a lane with nothing to add leaves its part alone
     if (e - s > heavy_t) {
-        if (sub == 0) {
-            uint32_t nch = (e - s + chunk - 1) / chunk;
-            uint32_t slot = atomicAdd(&heavy_counts[1], nch);
-            uint32_t hb = atomicAdd(&heavy_counts[0], 1u);
-            HeavyBucket h = {b, slot, nch, 0};
-            heavy_buckets[hb] = h;
-            for (uint32_t q = 0; q < nch; q++) {
-                HeavyChunk ch = {s + q * chunk, (s + (q + 1) * chunk < e) ? s + (q + 1) * chunk : e};
-                heavy_chunks[slot + q] = ch;
-            }
-        }
+        store = store && sub != 0;  // the bucket's first part belongs to the heavy role (which runs beside this lane); the others are identities
     } else if (s + sub < e) {
         // The point of the next entry is fetched before the current addition starts: with a window table the points
         // are gathers from hundreds of MB of HBM, and one addition (~2.3 k instructions) hides the whole miss.  The fetch
         // is an LDS-DMA (global_load_lds_dwordx4, per-lane source address, lane-linear destination): holding the next
         // point in registers instead costs 16 of them and with that the fourth wave per SIMD.
-        __shared__ uint4 pbuf[4][4][64];  // [wave][16-byte chunk of the point][lane]
+        typedef uint4 (*PBuf)[4][64];  // [wave][16-byte chunk of the point][lane]
+        const PBuf pbuf = reinterpret_cast<PBuf>(lds_raw);
         const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         auto issue = [&](uint32_t v) {
             const char* g = reinterpret_cast<const char*>(&bases[v & 0x7fffffffu]);
@@ -630,15 +655,19 @@ __device__ __forceinline__ XYZZu block_tree_sum_q(const XYZZu& v, XYZZu* sh) {
     return sh[0];
 }
 
-// B-heavy 1: workgroups stride over the chunk list; every wave exits once its index passes the count.  A lane's entries (four of a
-// 1024-entry chunk) are read up front and the next point is fetched before the current addition.
-__global__ void __launch_bounds__(256) msm_heavy_chunk_kernel(const Affine* __restrict__ bases, const uint32_t* __restrict__ vals,
-                                                              const uint32_t* __restrict__ heavy_counts, const HeavyChunk* __restrict__ heavy_chunks,
-                                                              XYZZu* __restrict__ chunk_sums) {
-    __shared__ XYZZu sh[256];
+// The heavy role: the first `hgrid` workgroups of msm_accum_kernel stride over the chunk list (on uniform scalars it is empty and they
+// leave at once).  A lane's entries (four of a 1024-entry chunk) are read up front and the next point is fetched before the current
+// addition; the chunk's 256 lane sums meet in a tree of quad additions.  The workgroup that finishes a bucket's LAST chunk (arrival
+// counter, as in msm_final_quad_kernel) sums the bucket's chunk sums and puts the total into the bucket's first part -- stored in a
+// fresh run, added in a continued one; the accumulate lanes leave that part alone, so the two roles never touch the same word.
+__device__ __noinline__ void msm_heavy_role(const Affine* __restrict__ bases, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ heavy_counts,
+                                            HeavyBucket* __restrict__ heavy_buckets, const HeavyChunk* __restrict__ heavy_chunks,
+                                            XYZZu* __restrict__ chunk_sums, uint32_t split_log, uint32_t cont, XYZZu* __restrict__ parts, uint32_t hgrid,
+                                            XYZZu* sh) {
+    __shared__ uint32_t last_flag;
     const uint32_t total = heavy_counts[1];
-    for (uint32_t ci = blockIdx.x; ci < total; ci += gridDim.x) {
-        HeavyChunk ch = heavy_chunks[ci];
+    for (uint32_t ci = blockIdx.x; ci < total; ci += hgrid) {
+        const HeavyChunk ch = heavy_chunks[ci];
         XYZZu acc = xyzzu_identity();
         uint32_t i = ch.begin + threadIdx.x;
         if (i < ch.end) {
@@ -653,28 +682,28 @@ __global__ void __launch_bounds__(256) msm_heavy_chunk_kernel(const Affine* __re
             }
             xyzzu_add_affine<FqU>(acc, p, (v >> 31) != 0);
         }
-        XYZZu r = block_tree_sum_q(acc, sh);
-        if (threadIdx.x == 0) chunk_sums[ci] = r;
-        __syncthreads();
-    }
-}
-
-// B-heavy 2: one workgroup per over-full bucket adds its chunk sums to the bucket's first part (the accumulate kernel left the
-// bucket's parts alone: identities in a fresh run, the sums of the earlier chunks in a streamed one)
-__global__ void __launch_bounds__(256) msm_heavy_final_kernel(const uint32_t* __restrict__ heavy_counts, const HeavyBucket* __restrict__ heavy_buckets,
-                                                              const XYZZu* __restrict__ chunk_sums, uint32_t split_log, XYZZu* __restrict__ parts) {
-    __shared__ XYZZu sh[256];
-    const uint32_t total = heavy_counts[0];
-    for (uint32_t hi = blockIdx.x; hi < total; hi += gridDim.x) {
-        HeavyBucket h = heavy_buckets[hi];
-        XYZZu acc = xyzzu_identity();
-        for (uint32_t q = threadIdx.x; q < h.n_chunks; q += blockDim.x) xyzzu_add(acc, chunk_sums[h.first_chunk + q]);
-        XYZZu r = block_tree_sum_q(acc, sh);
+        const XYZZu r = block_tree_sum_q(acc, sh);
         if (threadIdx.x == 0) {
-            XYZZu* dst = parts + ((size_t)h.bucket << split_log);
-            XYZZu cur = *dst;
-            xyzzu_add(cur, r);
-            *dst = cur;
+            chunk_sums[ci] = r;
+            __threadfence();
+            last_flag = atomicAdd(&heavy_buckets[ch.owner].arrived, 1u) + 1 == heavy_buckets[ch.owner].n_chunks;
+        }
+        __syncthreads();
+        if (last_flag) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const HeavyBucket h = heavy_buckets[ch.owner];
+            XYZZu sum = xyzzu_identity();
+            for (uint32_t q = threadIdx.x; q < h.n_chunks; q += blockDim.x) xyzzu_add(sum, chunk_sums[h.first_chunk + q]);
+            const XYZZu tot = block_tree_sum_q(sum, sh);
+            if (threadIdx.x == 0) {
+                XYZZu* dst = parts + ((size_t)h.bucket << split_log);
+                XYZZu cur = tot;
+                if (cont) {
+                    cur = *dst;
+                    xyzzu_add(cur, tot);
+                }
+                *dst = cur;
+            }
         }
         __syncthreads();
     }
@@ -966,7 +995,6 @@ static bool g_split_buckets = true;
 void msm_set_split_buckets(bool on) { g_split_buckets = on; }
 static bool g_quad_tail = true;
 void msm_set_quad_tail(bool on) { g_quad_tail = on; }
-static uint32_t g_accum_bs = 256;
 static bool g_global_order = true;  // false: bucket order local to a sort bin (measured 1.3-1.8x slower accumulation)
 void msm_set_bucket_order(int local) { g_global_order = local == 0; }
 void msm_set_bin_entries(size_t d) { g_bin_entries = d ? d : 8192; }
@@ -1256,11 +1284,11 @@ static int msm_stage_a(Ctx* c, const MsmLayout& L, char* base, const Fe* const* 
         hipLaunchKernelGGL(msm_l2_kernel<false>, dim3(L.C1), dim3(1024), 0, s, (const uint2*)(base + L.o_tmp), (const uint32_t*)nullptr,
                            (const uint16_t*)nullptr, cstart, L.L, L.bin_shift, vals, start, counts, perm, g_global_order ? hist : (uint32_t*)nullptr);
     H2_CHECK(hipGetLastError());
-    if (g_global_order) {
-        hipLaunchKernelGGL(msm_bucket_scatter_kernel, dim3((L.K + 1024 * MSM_BS_PER - 1) / (1024 * MSM_BS_PER)), dim3(1024), 0, s, counts, L.K, L.bin_shift,
-                           hist, perm);
-        H2_CHECK(hipGetLastError());
-    }
+    // size-ordered bucket permutation (skipped under the local-order debug knob) and the list of over-full buckets with their chunks
+    hipLaunchKernelGGL(msm_bucket_scatter_kernel, dim3((L.K + 1024 * MSM_BS_PER - 1) / (1024 * MSM_BS_PER)), dim3(1024), 0, s, (const uint32_t*)counts,
+                       (const uint32_t*)start, L.K, L.bin_shift, p.heavy_t, p.chunk, hist, g_global_order ? perm : (uint32_t*)nullptr,
+                       (uint32_t*)(base + L.o_hcnt), (HeavyBucket*)(base + L.o_hb), (HeavyChunk*)(base + L.o_hc));
+    H2_CHECK(hipGetLastError());
     c->timer_end(t1, s);
     return 0;
 }
@@ -1284,22 +1312,18 @@ static int msm_stage_b(Ctx* c, const MsmLayout& L, char* base, const Affine* d_p
     XYZZu* parts = (XYZZu*)(bbase + L.o_parts);
     const uint32_t lanes = L.K << L.split_log;
     const uint32_t cont_u = cont ? 1u : 0u;
+    // the first hgrid workgroups take the over-full buckets' chunks (none on uniform scalars: they leave at once), the rest one lane per part
+    const uint32_t hgrid = (uint32_t)(L.max_chunks < (size_t)c->sm_count ? L.max_chunks : (size_t)c->sm_count);
+    const dim3 agrid(hgrid + (lanes + 255) / 256);
     if (c->timer_kernel("msm_accum", &ke0, &ke1) >= 0)  // the dispatch's own begin / end timestamps: no marker packets around it
-        hipExtLaunchKernelGGL(msm_accum_kernel, dim3((lanes + g_accum_bs - 1) / g_accum_bs), dim3(g_accum_bs), 0, s, ke0, ke1, 0, d_points, vals, start,
-                              counts, perm, L.K, L.split_log, p.heavy_t, p.chunk, cont_u, parts, hcnt, hb, hc);
+        hipExtLaunchKernelGGL(msm_accum_kernel, agrid, dim3(256), 0, s, ke0, ke1, 0, d_points, (const uint32_t*)vals, (const uint32_t*)start,
+                              (const uint32_t*)counts, (const uint32_t*)perm, L.K, L.split_log, p.heavy_t, cont_u, parts, hgrid, (const uint32_t*)hcnt, hb,
+                              (const HeavyChunk*)hc, hs);
     else
-        hipLaunchKernelGGL(msm_accum_kernel, dim3((lanes + g_accum_bs - 1) / g_accum_bs), dim3(g_accum_bs), 0, s, d_points, vals, start, counts, perm,
-                           L.K, L.split_log, p.heavy_t, p.chunk, cont_u, parts, hcnt, hb, hc);
+        hipLaunchKernelGGL(msm_accum_kernel, agrid, dim3(256), 0, s, d_points, (const uint32_t*)vals, (const uint32_t*)start, (const uint32_t*)counts,
+                           (const uint32_t*)perm, L.K, L.split_log, p.heavy_t, cont_u, parts, hgrid, (const uint32_t*)hcnt, hb, (const HeavyChunk*)hc, hs);
     H2_CHECK(hipGetLastError());
     c->timer_end(t2, s);
-    int t3 = c->timer_begin("msm_heavy", s);
-    uint32_t hgrid = (uint32_t)(L.max_chunks < (size_t)c->sm_count * 4 ? L.max_chunks : (size_t)c->sm_count * 4);
-    hipLaunchKernelGGL(msm_heavy_chunk_kernel, dim3(hgrid), dim3(256), 0, s, d_points, vals, hcnt, hc, hs);
-    H2_CHECK(hipGetLastError());
-    uint32_t fgrid = (uint32_t)(L.max_heavy < (size_t)c->sm_count ? L.max_heavy : (size_t)c->sm_count);
-    hipLaunchKernelGGL(msm_heavy_final_kernel, dim3(fgrid), dim3(256), 0, s, hcnt, hb, hs, L.split_log, parts);
-    H2_CHECK(hipGetLastError());
-    c->timer_end(t3, s);
     if (L.split_log && combine) {
         const uint32_t comb_lanes = L.K << (L.split_log - 1);
         hipLaunchKernelGGL(msm_combine_kernel, dim3((comb_lanes + 255) / 256), dim3(256), 0, s, (const XYZZu*)parts, L.K, L.split_log, buckets);
