@@ -317,7 +317,7 @@ int h2hip_set_msm_window(uint32_t c);
 uint32_t h2hip_get_msm_window(size_t n);
 uint32_t h2hip_get_msm_window_fixed_base(size_t n);
 /* Per-stage HIP-event timers recorded on the stream each kernel group is launched on.
- * Stages: "ntt", "msm_total", "msm_digits", "msm_sort", "msm_accum", "msm_heavy", "msm_reduce", "g_to_lagrange", "kzg_setup". */
+ * Stages: "ntt", "msm_total", "msm_digits", "msm_sort", "msm_accum" (over-full buckets included), "msm_reduce", "g_to_lagrange", "kzg_setup". */
 /* on = 1: every stage (each event record costs the stream ~10 us of gap); on = 2: only the dominant kernel ("msm_accum"),
  * timed through its own dispatch packet with no gap; 0: off */
 int h2hip_profile_enable(int on);
