@@ -611,6 +611,62 @@ def test_batched_transforms_equal_single_ones(h2, oracle, k):
         assert torch.equal(g, w)
 
 
+@pytest.mark.gpu
+def test_batched_transforms_cut_into_several_launches(h2, oracle):
+    """A batch larger than the bytes one launch may span (2 GB by default; lowered to three columns' worth here with the tuning
+    hook) is cut into several launches per pass: nine columns of 2^14 -> 2^16, every one equal to the unbatched entry point"""
+    import ctypes
+    import torch
+    k = 14
+    d, _ = oracle.domain_new(4, k)
+    ek = d.extended_k
+    cols = [h2.gen_scalars_device(7000 + i, 1 << ek) for i in range(9)]
+    want = [c.clone() for c in cols]
+    for w in want:
+        h2.coeff_to_extended_device(w, k, ek, d.fe("extended_omega"), d.fe("g_coset"), d.fe("g_coset_inv"))
+    got = [c.clone() for c in cols]
+    try:
+        h2.lib().h2hip_debug_set_ntt_batch_bytes(ctypes.c_uint64(3 * 2 * (32 << ek)))  # columns + workspace of three
+        h2.coeff_to_extended_batch_device(got, k, ek, d.fe("extended_omega"), d.fe("g_coset"), d.fe("g_coset_inv"))
+        inv = [g.clone() for g in got]
+        h2.ifft_batch_device(inv, d.fe("extended_omega_inv"), ek, d.fe("extended_ifft_divisor"))
+    finally:
+        h2.lib().h2hip_debug_set_ntt_batch_bytes(ctypes.c_uint64(0))
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+    one = inv[0].clone()
+    h2.ntt_device(one, d.fe("extended_omega"), ek)
+    torch.cuda.synchronize()
+    assert torch.equal(one, got[0])  # and the cut inverse batch undoes a forward transform
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("j,k", [(9, 15), (9, 17), (3, 18)])
+def test_coeff_to_extended_other_padding_ratios_vs_oracle(h2, oracle, j, k):
+    """coeff_to_extended with the extended domain 8 x (quotient degree 8: the first pass skips its first stage pair as it does at 4 x,
+    two-pass plan at 2^20, three passes at 2^18) and 2 x (nothing to skip) the polynomial's length, against the oracle"""
+    import torch
+    d, _ = oracle.domain_new(j, k)
+    ek = d.extended_k
+    assert ek == k + (3 if j == 9 else 1)
+    a = oracle.gen_scalars(8100 + k, 1 << k)
+    want = oracle.coeff_to_extended(d, a, NT)
+    buf = torch.zeros((1 << ek, 4), dtype=torch.int64, device="cuda")
+    buf[:1 << k] = torch.from_numpy(a.view(np.int64)).cuda()
+    buf[1 << k:] = 0x5A5A  # whatever lies beyond the coefficients is not read
+    h2.coeff_to_extended_device(buf, k, ek, d.fe("extended_omega"), d.fe("g_coset"), d.fe("g_coset_inv"))
+    torch.cuda.synchronize()
+    assert np.array_equal(h2.to_numpy_u64(buf), want)
+    cols = [buf.clone() for _ in range(5)]  # and batched (2^19 / 2^20 columns: two-pass plan either way)
+    for c in cols:
+        c[:1 << k] = torch.from_numpy(a.view(np.int64)).cuda()
+    h2.coeff_to_extended_batch_device(cols, k, ek, d.fe("extended_omega"), d.fe("g_coset"), d.fe("g_coset_inv"))
+    torch.cuda.synchronize()
+    for c in cols:
+        assert np.array_equal(h2.to_numpy_u64(c), want)
+
+
 def test_batched_transforms_reject_bad_arguments(h2):
     import ctypes
     L = h2.lib()
