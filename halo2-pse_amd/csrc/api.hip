@@ -40,6 +40,7 @@ void ntt_set_two_pass(uint32_t lo, uint32_t hi);
 void ntt_set_full_twiddle_budget(uint64_t bytes);
 void ntt_set_batch_bytes(uint64_t bytes);
 void ntt_set_two_pass_log_j(int v);
+void ntt_set_full_max_log_m(uint32_t v);
 void ntt_set_two_pass_batch_wgs(uint64_t v);
 void msm_set_reserved_cus(uint32_t k);
 uint32_t msm_get_reserved_cus();
@@ -1961,6 +1962,12 @@ int h2hip_debug_set_ntt_batch_bytes(uint64_t bytes) {
 // tuning hook: workgroups per pass from which batched columns of 2^17..2^19 points take the two-pass plan (0 = default 1024)
 int h2hip_debug_set_ntt_two_pass_batch_wgs(uint64_t v) {
     ntt_set_two_pass_batch_wgs(v);
+    return 0;
+}
+
+// tuning hook: the largest strided pass (log2 of its M) that reads its inter-pass twiddles from a table (0 = default 20)
+int h2hip_debug_set_ntt_full_max_log_m(uint32_t v) {
+    ntt_set_full_max_log_m(v);
     return 0;
 }
 

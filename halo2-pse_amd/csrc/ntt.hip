@@ -453,6 +453,8 @@ static uint64_t g_ntt_full_budget = (uint64_t)1 << 30;  // HALO2_HIP_NTT_TWIDDLE
 void ntt_set_full_twiddle_budget(uint64_t bytes) { g_ntt_full_budget = bytes; }
 static size_t g_ntt_batch_bytes = (size_t)2 << 30;  // columns + workspace one batched launch may span (ntt_device_batch)
 void ntt_set_batch_bytes(uint64_t bytes) { g_ntt_batch_bytes = bytes ? (size_t)bytes : (size_t)2 << 30; }
+static uint32_t g_ntt_full_max_log_m = 20;  // strided passes of the three-pass plan read their inter-pass twiddles from a table up to 2^this entries
+void ntt_set_full_max_log_m(uint32_t v) { g_ntt_full_max_log_m = v ? v : 20; }
 static int g_ntt2_log_j = -1;  // tuning: columns per workgroup of the two-pass kernels (-1 = the plan's choice)
 void ntt_set_two_pass_log_j(int v) { g_ntt2_log_j = v; }
 
@@ -777,7 +779,7 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
             bind(t == 0 ? FIRST : DATA, t == P - 2 ? WS : DATA);
             // a table of up to 2^20 entries (38 MB) stays cache-resident next to the data: every strided pass but the first of a large transform
             p.tw_full = nullptr;
-            if (log_m <= 20 && t < 3) {
+            if (log_m <= g_ntt_full_max_log_m && t < 3) {
                 if ((rc = get_full_twiddles(c, omega, p, 1 + t, s, &tw))) return rc;
                 p.tw_full = g_ntt_full_budget ? tw.full[1 + t] : nullptr;
             }

@@ -54,6 +54,8 @@ int h2hip_debug_set_ntt_twiddle_budget(uint64_t bytes);
 int h2hip_debug_set_ntt_batch_bytes(uint64_t bytes);
 /* two-pass plan for batched columns of 2^17..2^19 points: from this many workgroups per pass (0 = default 1024) */
 int h2hip_debug_set_ntt_two_pass_batch_wgs(uint64_t v);
+/* three-pass plan: strided passes up to 2^v points read their inter-pass twiddles from a per-domain table (0 = default 20) */
+int h2hip_debug_set_ntt_full_max_log_m(uint32_t v);
 /* two-pass plan: log2 columns per workgroup (-1 = default) */
 int h2hip_debug_set_ntt_two_pass_log_j(int v);
 /* evaluate_h: programs needing more slots than v use the global-workspace form of the kernels (default 256) */
