@@ -63,6 +63,10 @@ struct TwiddleTable {
     // pass 1, slots 1..3 strided pass 0..2 of the other plan; tag = log_m << 8 | s
     Fu* full[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t full_tag[4] = {0, 0, 0, 0};
+    // `lo` times one constant (the 1/n of the inverse transform that uses this domain): a first pass that combines its inter-pass
+    // twiddles from the two-level table then scales for free, and the last pass closes with the direct reduction (ntt.hip ntt_run)
+    Fu* lo_scaled = nullptr;
+    Fe lo_scale;
 };
 
 // Fixed-base window table of a pinned base array (msm.hip): row j (of `stride` points) = 2^(c j) * P, j < W

@@ -444,6 +444,7 @@ void ntt_twiddles_free(Ctx* c) {
         if (t.stage[1] != t.stage[0]) (void)hipFree(t.stage[1]);
         (void)hipFree(t.stage[0]);
         for (int k = 0; k < 4; k++) (void)hipFree(t.full[k]);
+        (void)hipFree(t.lo_scaled);
     }
     c->twiddles.clear();
     c->tw_full_bytes = 0;
@@ -482,6 +483,39 @@ static int get_twiddles(Ctx* c, const Fe& omega, uint32_t log_n, hipStream_t s, 
     }
     c->twiddles[key] = t;
     *out = t;
+    return 0;
+}
+
+__global__ void twiddle_scale_kernel(const Fu* __restrict__ in, Fu* __restrict__ out, uint32_t n, Fu scale_i) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fu_norm(fu_mul<FrU>(in[i], scale_i));  // I * I -> I
+}
+
+// the domain's `lo` table times `scale` (cached; one constant per domain: a second one replaces it)
+static int get_scaled_lo(Ctx* c, const Fe& omega, uint32_t log_n, const Fe& scale, hipStream_t s, const Fu** out) {
+    TwiddleKey key;
+    for (int i = 0; i < 8; i++) key.omega[i] = omega.l[i];
+    key.log_n = log_n;
+    auto it = c->twiddles.find(key);
+    if (it == c->twiddles.end()) {
+        set_error("ntt: scaled twiddles asked before the domain's table");
+        return 1;
+    }
+    TwiddleTable& t = it->second;
+    if (t.lo_scaled && memcmp(&t.lo_scale, &scale, sizeof(Fe)) != 0) {
+        H2_CHECK(hipDeviceSynchronize());
+        (void)hipFree(t.lo_scaled);
+        t.lo_scaled = nullptr;
+    }
+    if (!t.lo_scaled) {
+        const uint32_t n_lo = 1u << t.lo_bits;
+        H2_CHECK(hipMalloc((void**)&t.lo_scaled, (size_t)n_lo * sizeof(Fu)));
+        hipLaunchKernelGGL(twiddle_scale_kernel, dim3((n_lo + 255) / 256), dim3(256), 0, s, (const Fu*)t.lo, t.lo_scaled, n_lo, fu_i_from_fe(scale));
+        H2_CHECK(hipGetLastError());
+        H2_CHECK(hipStreamSynchronize(s));  // built once per domain; later calls may use another stream
+        t.lo_scale = scale;
+    }
+    *out = t.lo_scaled;
     return 0;
 }
 
@@ -728,6 +762,7 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
     p.tw_lo = tw.lo;
     p.tw_hi = tw.hi;
     p.lo_bits = tw.lo_bits;
+    bool folded = false;
     if (two) {
         if (c->device >= 0 && c->device < 64 && !g_ntt2_attr[c->device]) {  // a 2^11-point image: more than the default 64 KB of dynamic LDS
             H2_CHECK(hipFuncSetAttribute((const void*)ntt2_strided_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
@@ -746,6 +781,18 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
             p.first = (t == 0);
             p.stage_tw = tw.stage[t];
             p.tw_full = t == 0 && g_ntt_full_budget ? tw.full[0] : nullptr;  // a zero budget also sets existing tables aside
+            if (t == 0 && !p.tw_full && p.out_scale == 2 && sc) {
+                // one output constant (the inverse's 1/n) and pass 1 combining its twiddles from the two-level table: the constant rides in a
+                // scaled copy of `lo`, and pass 2 closes with the direct reduction instead of the multiply
+                const Fu* lo_s = nullptr;
+                if ((rc = get_scaled_lo(c, omega, log_n, sc->out3[0], s, &lo_s))) return rc;
+                p.tw_lo = lo_s;
+                folded = true;
+            }
+            if (t == 1 && folded) {
+                p.tw_lo = tw.lo;
+                p.out_scale = 0;
+            }
             bind(t == 0 ? FIRST : WS, t == 0 ? WS : DATA);
             const dim3 grid(1u << (log_n - p.s - p.log_j), (uint32_t)count), block(1u << (p.s - 2));
             const size_t lds = sizeof(Fu) << p.s;
@@ -767,6 +814,8 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
         bool final = (t == P - 1);
         if (final) {
             p.tw_full = nullptr;
+            p.tw_lo = tw.lo;
+            if (folded) p.out_scale = 0;
             bind(P == 1 ? FIRST : WS, DATA);
             uint32_t log_nb = log_n - p.s;
             const uint32_t want_j = p.s <= 8 ? 2 : 1;  // 4 columns (128 B rows) up to 256-point tiles, 2 beyond: LDS
@@ -779,9 +828,16 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
             bind(t == 0 ? FIRST : DATA, t == P - 2 ? WS : DATA);
             // a table of up to 2^20 entries (38 MB) stays cache-resident next to the data: every strided pass but the first of a large transform
             p.tw_full = nullptr;
+            p.tw_lo = tw.lo;  // (before a table is built from it: pass_twiddle_build_kernel reads p)
             if (log_m <= g_ntt_full_max_log_m && t < 3) {
                 if ((rc = get_full_twiddles(c, omega, p, 1 + t, s, &tw))) return rc;
                 p.tw_full = g_ntt_full_budget ? tw.full[1 + t] : nullptr;
+            }
+            if (t == 0 && !p.tw_full && p.out_scale == 2 && sc) {  // as in the two-pass plan: the one output constant rides in the first pass's twiddles
+                const Fu* lo_s = nullptr;
+                if ((rc = get_scaled_lo(c, omega, log_n, sc->out3[0], s, &lo_s))) return rc;
+                p.tw_lo = lo_s;
+                folded = true;
             }
             uint32_t log_l = log_m - p.s;
             const uint32_t want_j = p.s <= 8 ? 2 : 1;

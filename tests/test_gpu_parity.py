@@ -210,11 +210,14 @@ def test_ntt_full_size_2p22_roundtrip_and_oracle(h2, oracle):
     assert np.array_equal(h2.to_numpy_u64(da), a)
 
 
-@pytest.mark.parametrize("k", [18, 19, 20, 21, 22])
+@pytest.mark.parametrize("k", [18, 19, 20, 21, 22, 23])
 def test_ntt_two_pass_plan_equals_three_pass(h2, oracle, k):
     """The two plans of ntt.hip (two passes of 2^9..2^11-point tiles, three of 2^6..2^8) give the same limbs for the plain
     transform, the scaled inverse and the zero-padded coset transform, with the inter-pass twiddles read from their per-domain table
-    or combined from the two-level one; the tuning hooks force each at every size."""
+    or combined from the two-level one; the tuning hooks force each at every size.  Where a first pass combines its twiddles from the
+    two-level table, the inverse's 1/n rides in a scaled copy of that table and the last pass closes with the direct reduction
+    (2^21 up on three passes -- with a table-fed second pass behind it --, 2^22 on two, every size under a zero budget); 2^23 has
+    only the three-pass plan, with and without tables."""
     import ctypes
     import torch
     L = h2.lib()
