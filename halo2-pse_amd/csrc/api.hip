@@ -1959,7 +1959,7 @@ int h2hip_debug_set_ntt_batch_bytes(uint64_t bytes) {
     return 0;
 }
 
-// tuning hook: workgroups per pass from which batched columns of 2^17..2^19 points take the two-pass plan (0 = default 1024)
+// tuning hook: pairs of workgroups per pass from which batched columns of 2^17 / 2^18 points take the two-pass plan (0 = default 512)
 int h2hip_debug_set_ntt_two_pass_batch_wgs(uint64_t v) {
     ntt_set_two_pass_batch_wgs(v);
     return 0;

@@ -47,6 +47,7 @@ struct NttPass {
     uint32_t first, in_scale;
     uint32_t out_scale;  // 0: none, 1: out3[oi % 3], 2: out3[0] for every output
     uint32_t n_prev;
+    uint32_t xgroup;     // two-pass plan, one column / block per workgroup: 2^xgroup neighbouring ones go to workgroups b, b + 8, ... (one XCD); 0: in order
     uint32_t prev_s[4];
     Fu in3[3], out3[3];  // I-form constants
     // batched launch (gridDim.y transforms of the same size): transform y reads srcs[y], writes dsts[y]
@@ -341,6 +342,13 @@ __device__ __forceinline__ void four(F&& f) {
     f(3u);
 }
 
+// workgroup b of a grid whose size is a multiple of 8 << g  ->  the item it takes, such that items i, i + 1, ..., i + 2^g - 1 (i a multiple
+// of 2^g) are taken by workgroups b, b + 8, ..., b + 8 (2^g - 1): the same XCD under the round-robin dispatch
+__device__ __forceinline__ uint64_t xcd_group(uint32_t b, uint32_t g) {
+    const uint32_t q = b >> (3 + g), r = b & ((8u << g) - 1);
+    return ((uint64_t)(q * 8 + (r & 7)) << g) | (r >> 3);
+}
+
 // pass 1 of 2: columns lo0 .. lo0 + J - 1 of the R x L view (L = N / R), rows at stride L.  A column's 32-byte pieces of a
 // row are read and written one column at a time.  Measured (FETCH_SIZE): the pass fetches 2.04 x what it consumes -- every
 // piece brings its 64-byte sector and the neighbouring column asks for it again after 16 MB have passed through the XCD's
@@ -351,7 +359,12 @@ __global__ void __launch_bounds__(512, 4) ntt2_strided_kernel(NttPass p) {
     Fu* x = reinterpret_cast<Fu*>(ntt_lds_raw);
     const uint32_t T = blockDim.x;  // R / 4
     const uint32_t log_l = p.log_n - p.s;
-    const uint64_t lo0 = (uint64_t)blockIdx.x << p.log_j;
+    // One column per workgroup.  Neighbouring columns share their rows' cache lines (a row piece is 32 B of a 128-byte line), and workgroups
+    // are dealt to the eight XCDs -- eight L2s -- in turn: 2^xgroup neighbouring columns go to workgroups b, b + 8, b + 16, ..., which land on
+    // ONE XCD at nearly the same time, so a line is fetched into (and written back from) one L2 once.  Measured against two columns per
+    // workgroup one after the other, whose second column found its sectors evicted: 2^20 0.143 -> 0.120 ms, 2^21 0.247 -> 0.219, 2^22 0.496 -> 0.462.
+    uint64_t lo0 = (uint64_t)blockIdx.x << p.log_j;
+    if (p.xgroup) lo0 = xcd_group(blockIdx.x, p.xgroup);
     const bool quarter = p.first && (p.in_len << 2) <= (1ull << p.log_n);  // rows T = R / 4 and up lie at T * L = N / 4 and beyond
 #pragma unroll 1
     for (uint32_t c = 0; c < (1u << p.log_j); c++) {
@@ -377,7 +390,8 @@ __global__ void __launch_bounds__(512, 4) ntt2_final_kernel(NttPass p) {
     Fu* x = reinterpret_cast<Fu*>(ntt_lds_raw);
     const uint32_t T = blockDim.x;  // R / 4
     const uint32_t log_nb = p.log_n - p.s;
-    const uint64_t v0 = (uint64_t)blockIdx.x << p.log_j;
+    uint64_t v0 = (uint64_t)blockIdx.x << p.log_j;
+    if (p.xgroup) v0 = xcd_group(blockIdx.x, p.xgroup);  // neighbouring blocks write neighbouring 32-byte pieces: pairs on one XCD (up to 2^21 points: -2 to -4 %; at 2^22 +2 %, not used)
 #pragma unroll 1
     for (uint32_t c = 0; c < (1u << p.log_j); c++) {
         const uint64_t vb = v0 + c;
@@ -644,18 +658,26 @@ int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const uint64_t* h_t, uint
 static uint32_t g_ntt_smax = 8;
 void ntt_set_smax(uint32_t v) { g_ntt_smax = v < 4 ? 4 : (v > 10 ? 10 : v); }
 // Sizes 2^lo..2^hi take the two-pass plan (tiles of 2^10 or 2^11 points, ntt2_*_kernel): measured on MI355X
-// (tools/ntt_two_pass.py) 14 % faster than three passes at 2^20, 9 % at 2^21, 5 % at 2^22; below, too few workgroups.
-// Batched columns of 2^17..2^19 points take it too once the batch brings g_ntt_two_batch_wgs workgroups per pass (a lone 2^19 transform
-// has 256: 0.117 against 0.089 ms; ten of them 0.059 against 0.070 ms each, ten of 2^17 0.018 against 0.022: tools/ntt_batch_rate.py).
-static uint32_t g_ntt_two_lo = 20, g_ntt_two_hi = 22, g_ntt_two_batch_lo = 17;
-static uint64_t g_ntt_two_batch_wgs = 1024;
+// (tools/ntt_two_pass.py) 14 % faster than three passes at 2^20, 9 % at 2^21, 5 % at 2^22 with two columns per workgroup, 25 / 19 / 12 % with one
+// (round 3); below 2^19 a lone transform brings too few workgroups.
+// Batched columns of 2^17 / 2^18 points take it too once the batch brings g_ntt_two_batch_wgs workgroup pairs per pass (tools/ntt_batch_rate.py, with one
+// column per workgroup: a lone 2^18 transform 0.068 against 0.052 ms for three passes, two of them 0.041 against 0.048 each; four of 2^17 0.021 / 0.026;
+// a lone 2^19 already 0.078 / 0.091).
+static uint32_t g_ntt_two_lo = 19, g_ntt_two_hi = 22, g_ntt_two_batch_lo = 17;
+static uint64_t g_ntt_two_batch_wgs = 512;
 static bool g_ntt2_attr[64];
 void ntt_set_two_pass(uint32_t lo, uint32_t hi) {
+    if (lo == 0 && hi == 0) {  // the defaults
+        g_ntt_two_lo = 19;
+        g_ntt_two_hi = 22;
+        g_ntt_two_batch_lo = 17;
+        return;
+    }
     g_ntt_two_lo = lo < 16 ? 16 : lo;
     g_ntt_two_hi = hi > 22 ? 22 : hi;
     g_ntt_two_batch_lo = g_ntt_two_lo < 17 ? g_ntt_two_lo : hi < lo ? 64 : 17;  // hi < lo turns the plan off altogether
 }
-void ntt_set_two_pass_batch_wgs(uint64_t v) { g_ntt_two_batch_wgs = v ? v : 1024; }
+void ntt_set_two_pass_batch_wgs(uint64_t v) { g_ntt_two_batch_wgs = v ? v : 512; }
 
 // pass radices: one pass up to 2^10, otherwise ceil(log_n / smax) passes of near-equal radix
 static int plan_passes(uint32_t log_n, uint32_t s_out[4]) {
@@ -774,11 +796,16 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
         // no longer do and the table costs 7 % instead
         p.log_m = log_n;
         if (log_n <= 21 && (rc = get_full_twiddles(c, omega, p, 0, s, &tw))) return rc;
-        p.log_j = 1;  // two columns (64-byte rows): four halve the workgroups and measure 6 % slower at 2^22, 24 % at 2^20
+        p.log_j = 0;  // one column / block per workgroup, neighbours grouped per XCD (ntt2_strided_kernel); two columns one after the other: see there
         if (g_ntt2_log_j >= 0 && g_ntt2_log_j <= 3) p.log_j = (uint32_t)g_ntt2_log_j;
         for (int t = 0; t < 2; t++) {
             p.s = S[t];
             p.first = (t == 0);
+            {
+                const uint32_t log_grid = log_n - p.s - p.log_j;
+                const uint32_t want = t == 0 ? 2u : (log_n <= 21 ? 1u : 0u);  // pass 1: four columns = one 128-byte line; pass 2: pairs while the transform stays in the Infinity Cache
+                p.xgroup = (p.log_j == 0 && log_grid >= 3 + want) ? want : 0;
+            }
             p.stage_tw = tw.stage[t];
             p.tw_full = t == 0 && g_ntt_full_budget ? tw.full[0] : nullptr;  // a zero budget also sets existing tables aside
             if (t == 0 && !p.tw_full && p.out_scale == 2 && sc) {

@@ -48,11 +48,12 @@ int h2hip_debug_set_msm_fuse_small(int on);
 /* largest log2 tile of an NTT pass (4..10; default 8, 9 beyond 2^24 points) */
 int h2hip_debug_set_ntt_smax(uint32_t v);
 int h2hip_debug_set_lazy_pin(uint32_t after);
+/* sizes 2^lo..2^hi take the two-pass plan (default 19..22; hi < lo: never; 0, 0: back to the defaults) */
 int h2hip_debug_set_ntt_two_pass(uint32_t lo, uint32_t hi);
 int h2hip_debug_set_ntt_twiddle_budget(uint64_t bytes);
 /* batched transforms: bytes of columns + workspace one launch spans (0 = default) */
 int h2hip_debug_set_ntt_batch_bytes(uint64_t bytes);
-/* two-pass plan for batched columns of 2^17..2^19 points: from this many workgroups per pass (0 = default 1024) */
+/* two-pass plan for batched columns of 2^17 / 2^18 points: from this many pairs of workgroups per pass (0 = default 512) */
 int h2hip_debug_set_ntt_two_pass_batch_wgs(uint64_t v);
 /* three-pass plan: strided passes up to 2^v points read their inter-pass twiddles from a per-domain table (0 = default 20) */
 int h2hip_debug_set_ntt_full_max_log_m(uint32_t v);

@@ -240,7 +240,7 @@ def test_ntt_two_pass_plan_equals_three_pass(h2, oracle, k):
             torch.cuda.synchronize()
             out[plan] = (f, i, e, b)
     finally:
-        L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(20), ctypes.c_uint32(22))
+        L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(0), ctypes.c_uint32(0))
         L.h2hip_debug_set_ntt_twiddle_budget(ctypes.c_uint64(1 << 30))
     for plan, res in out.items():
         for x, y in zip(res, out["three"]):

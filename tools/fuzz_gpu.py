@@ -62,7 +62,7 @@ for k in range(1, 23):
         y = x.clone(); h2.ifft_device(y, d.omega_inv, k, d.ifft_divisor)
         torch.cuda.synchronize()
         outs.append((x, torch.equal(y, a)))
-    L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(20), ctypes.c_uint32(22))
+    L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(0), ctypes.c_uint32(0))
     L.h2hip_debug_set_ntt_twiddle_budget(ctypes.c_uint64(1 << 30))
     ok = all(torch.equal(o[0], outs[0][0]) and o[1] for o in outs)
     if k <= 16:
@@ -90,7 +90,7 @@ for it in range(int(os.environ.get("COSET_CASES", "24"))):
     got = [c.clone() for c in cols]
     h2.coeff_to_extended_batch_device(got, k, ek, d.extended_omega, d.g_coset, d.g_coset_inv)
     L.h2hip_debug_set_ntt_two_pass_batch_wgs(ctypes.c_uint64(0))
-    L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(20), ctypes.c_uint32(22))
+    L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(0), ctypes.c_uint32(0))
     got2 = [c.clone() for c in cols]
     h2.coeff_to_extended_batch_device(got2, k, ek, d.extended_omega, d.g_coset, d.g_coset_inv)  # the library's own choice of plan
     torch.cuda.synchronize()
