@@ -138,6 +138,9 @@ __device__ __forceinline__ Fe fr_to_canonical(const Fe& x) {
 // WERE the two passes: they top out near 60 and 20 G/s chip-wide.  Bucket id of (MSM y, window w, slot) =
 // (set << cb) | slot with set = y (fixed-base) or y * W + w.
 #define MSM_TCHUNK 64u  // tiles per chunk of the offset computation
+#ifndef MSM_SCATTER_XG
+#define MSM_SCATTER_XG 4u  // log2 of the tiles of the scatter pass that share an XCD (0: workgroups take the tiles in order); A/B builds: 2, 3, 4, 6 -> sort of 2^24 pairs 1.89, 1.87, 1.85, 1.84 ms (2.02 in order)
+#endif
 
 // A1: histogram of the tile over the coarse bins
 __global__ void __launch_bounds__(256) msm_l1_count_kernel(L1Args a) {
@@ -222,11 +225,19 @@ __global__ void __launch_bounds__(1024) msm_l1_scatter_kernel(L1Args a) {
     __shared__ uint32_t cur[MSM_MAX_C1];   // entries per bin, then the bin's cursor in `stage`
     __shared__ uint32_t delta[MSM_MAX_C1]; // (position in tmp) - (position in stage) of the bin's run (mod 2^32)
     __shared__ uint32_t ps[16];
-    const size_t row = (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * a.C1;
+    // consecutive tiles write consecutive runs of every bin: groups of 2^XG tiles are dealt to ONE XCD (workgroups b, b + 8, ...), so that the
+    // cache lines two runs share meet in one L2
+    constexpr uint32_t XG = MSM_SCATTER_XG;
+    uint32_t tx = blockIdx.x;
+    if (XG && tx < (gridDim.x & ~((8u << XG) - 1))) {
+        const uint32_t q = tx >> (3 + XG), r = tx & ((8u << XG) - 1);
+        tx = ((q * 8 + (r & 7)) << XG) | (r >> 3);
+    }
+    const size_t row = (size_t)(blockIdx.y * gridDim.x + tx) * a.C1;
     for (uint32_t b = threadIdx.x; b < a.C1; b += 1024) cur[b] = a.tile_hist[row + b];
     const Fe* __restrict__ scalars = a.list ? a.list[blockIdx.y] : a.scalars_one;
     const uint32_t set0 = a.shared ? blockIdx.y : blockIdx.y * a.W;
-    const uint32_t i = blockIdx.x * a.tile + threadIdx.x;
+    const uint32_t i = tx * a.tile + threadIdx.x;
     const bool live = threadIdx.x < a.tile && i < a.n;
     Fe sc;
     if (live) sc = fr_to_canonical(scalars[i]);
