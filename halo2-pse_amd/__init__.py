@@ -147,6 +147,19 @@ def best_fft(a, omega, log_n):
     _check(lib().h2hip_ntt_bn254_fr(_p(a), _p(_fe(omega)), ctypes.c_uint32(log_n)), "h2hip_ntt_bn254_fr")
 
 
+def _host_ptrs(arrays):
+    return (ctypes.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
+
+
+def best_fft_batch(columns, omega, log_n):
+    """`len(columns)` in-place best_fft calls on host columns as one pipelined call (upload i + 1 | transform i | download i - 1)"""
+    for a in columns:
+        assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"] and a.shape == (1 << log_n, 4)
+    if columns:
+        _check(lib().h2hip_ntt_bn254_fr_batch(_host_ptrs(columns), ctypes.c_size_t(len(columns)), _p(_fe(omega)), ctypes.c_uint32(log_n)),
+               "h2hip_ntt_bn254_fr_batch")
+
+
 def g_to_lagrange(g, k):
     """arithmetic::g_to_lagrange (arithmetic.rs:277-301): (2^k, 8) affine points -> (2^k, 8) affine points"""
     g = _u64(g, 8)
@@ -357,6 +370,42 @@ class EvaluationDomain:
                "h2hip_extended_to_coeff_bn254_fr")
         return a[: self.n * self.quotient_poly_degree]
 
+
+    # the same conversions for a list of host columns, pipelined over PCIe inside one call (h2hip_*_batch): what a patched
+    # prover calls where the reference maps the single-column method over its polynomials (plonk/prover.rs:476-490,
+    # plonk/evaluation.rs:306-323)
+    def lagrange_to_coeff_batch(self, polys):
+        self._device_field()
+        cols = [_u64(a, 4).copy() for a in polys]
+        for a in cols:
+            assert a.shape[0] == 1 << self.k
+        if cols:
+            _check(lib().h2hip_ifft_bn254_fr_batch(_host_ptrs(cols), ctypes.c_size_t(len(cols)), _p(self.omega_inv), ctypes.c_uint32(self.k),
+                                                   _p(self.ifft_divisor)), "h2hip_ifft_bn254_fr_batch")
+        return cols
+
+    def coeff_to_extended_batch(self, polys):
+        self._device_field()
+        cols = [_u64(a, 4) for a in polys]
+        for a in cols:
+            assert a.shape[0] == 1 << self.k
+        outs = [np.empty((self.extended_len(), 4), dtype=np.uint64) for _ in cols]
+        if cols:
+            _check(lib().h2hip_coeff_to_extended_bn254_fr_batch(_host_ptrs(cols), ctypes.c_uint32(self.k), _host_ptrs(outs), ctypes.c_size_t(len(cols)),
+                                                                ctypes.c_uint32(self.extended_k), _p(self.extended_omega), _p(self.g_coset),
+                                                                _p(self.g_coset_inv)), "h2hip_coeff_to_extended_bn254_fr_batch")
+        return outs
+
+    def extended_to_coeff_batch(self, polys):
+        self._device_field()
+        cols = [_u64(a, 4).copy() for a in polys]
+        for a in cols:
+            assert a.shape[0] == self.extended_len()
+        if cols:
+            _check(lib().h2hip_extended_to_coeff_bn254_fr_batch(_host_ptrs(cols), ctypes.c_size_t(len(cols)), ctypes.c_uint32(self.extended_k),
+                                                                _p(self.extended_omega_inv), _p(self.extended_ifft_divisor), _p(self.g_coset),
+                                                                _p(self.g_coset_inv)), "h2hip_extended_to_coeff_bn254_fr_batch")
+        return [a[: self.n * self.quotient_poly_degree] for a in cols]
 
     def divide_by_vanishing_poly(self, a, t_evaluations=None):
         """poly/domain.rs:307-326"""

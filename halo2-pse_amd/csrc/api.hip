@@ -6,7 +6,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <shared_mutex>
 #include <thread>
@@ -445,6 +447,145 @@ static int on_devices(int n_use, const std::function<int(int)>& f) {
     return rc;
 }
 
+// ---- copier threads (engine.h) ----------------------------------------------------------------------------------------------
+struct Copier {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;       // work for the thread
+    std::condition_variable done_cv;  // progress for a blocked copier_wait
+    std::deque<CopyJob> q;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    bool quit = false;
+    size_t popped = 0;  // jobs taken off the queue this session (under m)
+    std::atomic<size_t> done{0};
+    std::atomic<int> err{0};
+    std::atomic<int> waiters{0};
+};
+
+static void copier_main(Copier* cp) {
+    (void)hipSetDevice(cp->device);
+    std::unique_lock<std::mutex> lk(cp->m);
+    for (;;) {
+        cp->cv.wait(lk, [&] { return !cp->q.empty() || cp->quit; });
+        if (cp->quit) return;
+        const CopyJob j = cp->q.front();
+        cp->q.pop_front();
+        cp->popped++;
+        hipStream_t st = cp->stream;
+        lk.unlock();
+        if (!cp->err.load(std::memory_order_relaxed)) {
+            hipError_t e = j.gate ? hipStreamWaitEvent(st, j.gate, 0) : hipSuccess;
+            if (e == hipSuccess) e = hipMemcpyAsync(j.dst, j.src, j.bytes, j.d2h ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice, st);
+            if (e == hipSuccess && j.ev) e = hipEventRecord(j.ev, st);
+            if (e != hipSuccess) cp->err.store((int)e);
+        }
+        cp->done.fetch_add(1);
+        lk.lock();
+        if (cp->waiters.load()) cp->done_cv.notify_all();
+    }
+}
+
+bool copier_ready(Ctx* c, bool down) {
+    Copier*& cp = c->copier[down ? 1 : 0];
+    if (cp) return true;
+    try {
+        cp = new Copier();
+        cp->device = c->device;
+        cp->th = std::thread(copier_main, cp);
+    } catch (...) {  // no memory / no thread: nothing may unwind across the C ABI; the caller takes its unstreamed path
+        if (cp) delete cp;
+        cp = nullptr;
+        set_error("copier thread for device %d could not be started", c->device);
+        return false;
+    }
+    return true;
+}
+
+int copier_begin(Ctx* c, bool down, hipStream_t stream) {
+    if (!copier_ready(c, down)) return H2HIP_ENOMEM;
+    Copier* cp = c->copier[down ? 1 : 0];
+    std::lock_guard<std::mutex> lk(cp->m);
+    if (!cp->q.empty()) {  // a session is over only when its jobs are (copier_abort on every error path)
+        set_error("copier: previous session still has jobs queued");
+        return H2HIP_EDEVICE;
+    }
+    cp->stream = stream;
+    cp->popped = 0;
+    cp->done.store(0);
+    cp->err.store(0);
+    return 0;
+}
+
+int copier_push(Ctx* c, bool down, std::vector<CopyJob>& jobs) {
+    Copier* cp = c->copier[down ? 1 : 0];
+    try {
+        std::lock_guard<std::mutex> lk(cp->m);
+        for (const CopyJob& j : jobs) cp->q.push_back(j);
+        cp->cv.notify_all();
+    } catch (...) {
+        set_error("copier: out of memory");
+        return H2HIP_ENOMEM;
+    }
+    jobs.clear();
+    return 0;
+}
+
+static void copier_block_until(Copier* cp, size_t n_jobs) {
+    // a job is tens to hundreds of microseconds away: spin briefly (the enqueueing thread wants to react within a launch latency),
+    // then sleep on the condition variable instead of holding a host core through a 10-ms upload
+    for (uint32_t spins = 0; spins < 4000; spins++)
+        if (cp->done.load(std::memory_order_acquire) >= n_jobs) return;
+    cp->waiters.fetch_add(1);
+    {
+        std::unique_lock<std::mutex> lk(cp->m);
+        cp->done_cv.wait(lk, [&] { return cp->done.load() >= n_jobs; });
+    }
+    cp->waiters.fetch_sub(1);
+}
+
+int copier_wait(Ctx* c, bool down, size_t n_jobs) {
+    Copier* cp = c->copier[down ? 1 : 0];
+    copier_block_until(cp, n_jobs);
+    if (int e = cp->err.load()) {
+        set_error("%s copy of a streamed piece failed: %s", down ? "device-to-host" : "host-to-device", hipGetErrorString((hipError_t)e));
+        return H2HIP_EDEVICE;
+    }
+    return 0;
+}
+
+void copier_abort(Ctx* c, bool down, size_t n_jobs) {
+    Copier* cp = c->copier[down ? 1 : 0];
+    if (!cp || cp->done.load(std::memory_order_acquire) >= n_jobs) return;
+    {
+        std::lock_guard<std::mutex> lk(cp->m);
+        if (cp->q.empty() && cp->done.load() == cp->popped) return;  // idle already
+    }
+    if (!cp->err.load()) cp->err.store((int)hipErrorUnknown);  // the jobs not yet started are skipped (and still counted)
+    for (;;) {  // idle = nothing queued and every popped job counted: the thread no longer touches the caller's memory or events
+        {
+            std::lock_guard<std::mutex> lk(cp->m);
+            if (cp->q.empty() && cp->done.load() == cp->popped) return;
+        }
+        std::this_thread::yield();
+    }
+}
+
+void copier_stop(Ctx* c) {
+    for (int k = 0; k < 2; k++) {
+        Copier* cp = c->copier[k];
+        if (!cp) continue;
+        {
+            std::lock_guard<std::mutex> lk(cp->m);
+            cp->quit = true;
+            cp->cv.notify_all();
+        }
+        cp->th.join();
+        delete cp;
+        c->copier[k] = nullptr;
+    }
+}
+
 static bool unpin_everywhere(const void* key);
 static bool pinned_validate(const uint64_t* bases_xy, size_t n);
 
@@ -638,6 +779,114 @@ static int ntt_host(uint64_t* a, const Fe& omega, uint32_t log_n, const NttScale
     H2_CHECK(hipMemcpyAsync(a, c->ntt_io.p, bytes, hipMemcpyDeviceToHost, c->stream));
     H2_CHECK(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+// ---- host-pointer batched transforms: a three-stage pipeline over the columns ----------------------------------------------------
+// create_proof converts its columns back to back from `Vec<F>`s (plonk/prover.rs:487 lagrange_to_coeff per advice column,
+// plonk/evaluation.rs:306-323 coeff_to_extended per advice / instance column).  One call each means upload -> transform ->
+// download in series, 11.6 x the device-resident transform at 2^22 (round 3).  Here column i + 1 crosses PCIe upwards and column
+// i - 1 downwards (full duplex, one copier thread per direction: pageable hipMemcpyAsync blocks its caller) while column i is
+// transformed on the engine's stream: per column max(upload, transform, download) instead of their sum.
+static size_t g_ntt_host_batch_bytes = (size_t)4 << 30;  // device memory one pipelined run may hold; larger batches are cut into runs
+static size_t g_ntt_host_group_bytes = (size_t)2 << 20;  // columns smaller than this are grouped per pipeline step
+
+struct PipeDrain {  // every exit: the copiers idle, their streams drained -- nothing touches the caller's columns after the call
+    Ctx* c;
+    hipStream_t su, sd;
+    ~PipeDrain() {
+        copier_abort(c, false, SIZE_MAX);
+        copier_abort(c, true, SIZE_MAX);
+        (void)hipStreamSynchronize(su);
+        (void)hipStreamSynchronize(sd);
+    }
+};
+
+// m columns: in[i] (in_elems elements) -> out[i] (2^log_n elements); in[i] == out[i] is fine (every column is read before it is written)
+static int ntt_host_pipeline(Ctx* c, const uint64_t* const* in, size_t in_elems, uint64_t* const* out, size_t m, const Fe& omega, uint32_t log_n,
+                             const NttScale* sc) {
+    const size_t col = sizeof(Fe) << log_n, in_bytes = in_elems * sizeof(Fe);
+    size_t gc = g_ntt_host_group_bytes / col;
+    if (gc < 1) gc = 1;
+    const size_t G = (m + gc - 1) / gc;
+    int rc;
+    if ((rc = c->ntt_io.ensure(m * col))) return rc;
+    if ((rc = c->ensure_aux(2 * G + 2))) return rc;
+    hipStream_t s = c->stream, su = c->aux2, sd = c->aux1;
+    hipEvent_t* ev = c->aux_events.data();  // [2g] group g uploaded, [2g + 1] group g transformed
+    char* base = (char*)c->ntt_io.p;
+    H2_CHECK(hipStreamSynchronize(s));
+    if ((rc = copier_begin(c, false, su))) return rc;
+    if ((rc = copier_begin(c, true, sd))) return rc;
+    PipeDrain drain{c, su, sd};
+    std::vector<CopyJob> jobs;
+    std::vector<Fe*> cols(m);
+    for (size_t i = 0; i < m; i++) {
+        cols[i] = (Fe*)(base + i * col);
+        jobs.push_back(CopyJob{cols[i], in[i], in_bytes, ((i + 1) % gc == 0 || i + 1 == m) ? ev[2 * (i / gc)] : nullptr, nullptr, false});
+    }
+    if ((rc = copier_push(c, false, jobs))) return rc;
+    for (size_t g = 0; g < G; g++) {
+        const size_t i0 = g * gc, cnt = m - i0 < gc ? m - i0 : gc;
+        if ((rc = copier_wait(c, false, i0 + cnt))) return rc;
+        H2_CHECK(hipStreamWaitEvent(s, ev[2 * g], 0));
+        rc = cnt == 1 ? ntt_device(c, cols[i0], omega, log_n, sc, s) : ntt_device_batch(c, cols.data() + i0, nullptr, cnt, omega, log_n, sc, s);
+        if (rc) return rc;
+        H2_CHECK(hipEventRecord(ev[2 * g + 1], s));
+        for (size_t i = i0; i < i0 + cnt; i++) jobs.push_back(CopyJob{out[i], cols[i], col, nullptr, i == i0 ? ev[2 * g + 1] : nullptr, true});
+        if ((rc = copier_push(c, true, jobs))) return rc;
+    }
+    if ((rc = copier_wait(c, true, m))) return rc;
+    H2_CHECK(hipStreamSynchronize(sd));
+    H2_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+
+static int ntt_host_batch_on(Ctx* c, const uint64_t* const* in, size_t in_elems, uint64_t* const* out, size_t count, const Fe& omega, uint32_t log_n,
+                             const NttScale* sc) {
+    const size_t col = sizeof(Fe) << log_n;
+    size_t per = g_ntt_host_batch_bytes / col;
+    if (per < 2) per = 2;
+    const bool threads = count > 1 && copier_ready(c, false) && copier_ready(c, true);
+    for (size_t i0 = 0; i0 < count; i0 += per) {
+        const size_t m = count - i0 < per ? count - i0 : per;
+        if (m > 1 && threads) {
+            int rc = ntt_host_pipeline(c, in + i0, in_elems, out + i0, m, omega, log_n, sc);
+            if (rc) return rc;
+            continue;
+        }
+        for (size_t i = i0; i < i0 + m; i++) {  // a lone column (or no copier threads): upload, transform, download in order
+            int rc = c->ntt_io.ensure(col);
+            if (rc) return rc;
+            H2_CHECK(hipMemcpyAsync(c->ntt_io.p, in[i], in_elems * sizeof(Fe), hipMemcpyHostToDevice, c->stream));
+            if ((rc = ntt_device(c, (Fe*)c->ntt_io.p, omega, log_n, sc, c->stream))) return rc;
+            H2_CHECK(hipMemcpyAsync(out[i], c->ntt_io.p, col, hipMemcpyDeviceToHost, c->stream));
+            H2_CHECK(hipStreamSynchronize(c->stream));
+        }
+    }
+    return 0;
+}
+
+// NTT replicas (second bullet): with several devices the columns are dealt in contiguous shares, every device
+// runs the pipeline on its share over its own PCIe link; no column crosses xGMI.
+static int ntt_host_batch(const char* name, const uint64_t* const* in, size_t in_elems, uint64_t* const* out, size_t count, const Fe& omega,
+                          uint32_t log_n, const NttScale* sc) {
+    if (!count) return 0;
+    bool multi;
+    {
+        Entry en(name);
+        if (en.rc) return en.rc;
+        multi = g_devs.size() > 1 && count > 1;
+        if (!multi) return ntt_host_batch_on(en.c, in, in_elems, out, count, omega, log_n, sc);
+    }
+    Entry en(name, nullptr, true);
+    if (en.rc) return en.rc;
+    const size_t nd = g_devs.size() < count ? g_devs.size() : count;
+    return on_devices((int)nd, [&](int d) -> int {
+        const size_t lo = count * (size_t)d / nd, hi = count * ((size_t)d + 1) / nd;
+        Ctx* x = g_devs[(size_t)d];
+        H2_CHECK(hipSetDevice(x->device));
+        return ntt_host_batch_on(x, in + lo, in_elems, out + lo, hi - lo, omega, log_n, sc);
+    });
 }
 
 static void make_zeta_scale(NttScale* sc, bool into_coset, const uint64_t g_coset[4], const uint64_t g_coset_inv[4], const Fe* divisor) {
@@ -1725,6 +1974,65 @@ int h2hip_coeff_to_extended_bn254_fr_batch_device(void* const* d_a, size_t count
     make_zeta_scale(&sc, true, g_coset, g_coset_inv, nullptr);
     sc.in_len = 1ull << k;
     return batch_over_devices("h2hip_coeff_to_extended_bn254_fr_batch_device", d_a, count, stream, extended_k, fe_from_u64x4(extended_omega), &sc);
+}
+
+// ---- the same conversions on host columns, pipelined (ntt_host_batch)
+static int host_batch_args_ok(const uint64_t* const* in, uint64_t* const* out, size_t count, uint32_t log_n, const char* what) {
+    if (log_n > 28 || (count && (!in || !out))) {
+        set_error("%s: bad argument", what);
+        return 0;
+    }
+    for (size_t i = 0; i < count; i++)
+        if (!in[i] || !out[i]) {
+            set_error("%s: null column %zu", what, i);
+            return 0;
+        }
+    return 1;
+}
+
+int h2hip_ntt_bn254_fr_batch(uint64_t* const* a, size_t count, const uint64_t omega[4], uint32_t log_n) {
+    if (!omega || !host_batch_args_ok(a, a, count, log_n, "ntt_batch")) return H2HIP_EINVAL;
+    if (check_fr(omega, "omega")) return H2HIP_EINVAL;
+    return ntt_host_batch("h2hip_ntt_bn254_fr_batch", a, (size_t)1 << log_n, a, count, fe_from_u64x4(omega), log_n, nullptr);
+}
+
+int h2hip_ifft_bn254_fr_batch(uint64_t* const* a, size_t count, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4]) {
+    if (!omega_inv || !divisor || !host_batch_args_ok(a, a, count, log_n, "ifft_batch")) return H2HIP_EINVAL;
+    if (check_fr(omega_inv, "omega_inv") || check_fr(divisor, "divisor")) return H2HIP_EINVAL;
+    NttScale sc;
+    sc.out_scale = true;
+    sc.out3[0] = sc.out3[1] = sc.out3[2] = fe_from_u64x4(divisor);
+    return ntt_host_batch("h2hip_ifft_bn254_fr_batch", a, (size_t)1 << log_n, a, count, fe_from_u64x4(omega_inv), log_n, &sc);
+}
+
+int h2hip_coeff_to_extended_bn254_fr_batch(const uint64_t* const* a, uint32_t k, uint64_t* const* out, size_t count, uint32_t extended_k,
+                                           const uint64_t extended_omega[4], const uint64_t g_coset[4], const uint64_t g_coset_inv[4]) {
+    if (!extended_omega || !g_coset || !g_coset_inv || k > extended_k || !host_batch_args_ok(a, out, count, extended_k, "coeff_to_extended_batch"))
+        return H2HIP_EINVAL;
+    if (check_fr(extended_omega, "extended_omega") || check_fr(g_coset, "g_coset") || check_fr(g_coset_inv, "g_coset_inv")) return H2HIP_EINVAL;
+    NttScale sc;
+    make_zeta_scale(&sc, true, g_coset, g_coset_inv, nullptr);
+    sc.in_len = 1ull << k;
+    return ntt_host_batch("h2hip_coeff_to_extended_bn254_fr_batch", a, (size_t)1 << k, out, count, fe_from_u64x4(extended_omega), extended_k, &sc);
+}
+
+int h2hip_extended_to_coeff_bn254_fr_batch(uint64_t* const* a, size_t count, uint32_t extended_k, const uint64_t extended_omega_inv[4],
+                                           const uint64_t extended_ifft_divisor[4], const uint64_t g_coset[4], const uint64_t g_coset_inv[4]) {
+    if (!extended_omega_inv || !extended_ifft_divisor || !g_coset || !g_coset_inv || !host_batch_args_ok(a, a, count, extended_k, "extended_to_coeff_batch"))
+        return H2HIP_EINVAL;
+    if (check_fr(extended_omega_inv, "extended_omega_inv") || check_fr(extended_ifft_divisor, "extended_ifft_divisor") ||
+        check_fr(g_coset, "g_coset") || check_fr(g_coset_inv, "g_coset_inv"))
+        return H2HIP_EINVAL;
+    NttScale sc;
+    Fe div = fe_from_u64x4(extended_ifft_divisor);
+    make_zeta_scale(&sc, false, g_coset, g_coset_inv, &div);
+    return ntt_host_batch("h2hip_extended_to_coeff_bn254_fr_batch", a, (size_t)1 << extended_k, a, count, fe_from_u64x4(extended_omega_inv), extended_k, &sc);
+}
+
+int h2hip_debug_set_ntt_host_batch(uint64_t run_bytes, uint64_t group_bytes) {
+    g_ntt_host_batch_bytes = run_bytes ? (size_t)run_bytes : (size_t)4 << 30;
+    g_ntt_host_group_bytes = group_bytes ? (size_t)group_bytes : (size_t)2 << 20;
+    return 0;
 }
 
 int h2hip_g_to_lagrange_bn254_device(const void* d_g_xy, uint32_t k, void* d_g_lagrange_xy, void* stream) {

@@ -96,6 +96,8 @@ struct PinnedBases {
     size_t lo = 0, hi = 0;     // multi-GPU: this device holds points [lo, hi) of the caller's array (n = hi - lo)
 };
 
+struct Ctx;
+
 struct StageTimer {
     std::string name;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -104,7 +106,31 @@ struct StageTimer {
     bool pending = false;
 };
 
-struct Copier;  // msm.hip: helper thread that issues the host-to-device copies of a streamed MSM
+// ---- copier threads (api.hip): hipMemcpyAsync to or from the caller's pageable memory moves at PCIe speed but returns only
+// when its piece has crossed, so the thread that enqueues kernels must not sit in it.  Each device context has two helper
+// threads, one per direction (PCIe is full duplex: the uploads of column i + 1 and the downloads of column i - 1 overlap).
+// A copier walks a job queue in order; per job: wait for `gate` on its stream (an event the enqueueing thread has already
+// recorded), copy, record `ev`, bump `done`.  Users: the streamed host-slice MSM (msm.hip) and the host-pointer batched
+// transforms (api.hip, ntt_host_batch).
+struct CopyJob {
+    void* dst;
+    const void* src;
+    size_t bytes;
+    hipEvent_t ev;    // recorded on the copy stream after this job; nullptr: none
+    hipEvent_t gate;  // the copy stream waits for it before this job; nullptr: none
+    bool d2h;
+};
+struct Copier;
+// begin a session on c's upload (down = false) or download (down = true) copier -- started on first use --: `done` and the
+// error state are reset, later jobs go to `stream`.  H2HIP_ENOMEM / H2HIP_EDEVICE when the thread cannot be started.
+bool copier_ready(Ctx* c, bool down);  // the thread exists (started now if need be); false: it cannot be started, take the unstreamed path
+int copier_begin(Ctx* c, bool down, hipStream_t stream);
+// append jobs to the session (the vector is left empty)
+int copier_push(Ctx* c, bool down, std::vector<CopyJob>& jobs);
+// block until the first n_jobs jobs of the session have been issued (for pageable memory: have crossed); non-zero: a copy failed
+int copier_wait(Ctx* c, bool down, size_t n_jobs);
+// error-path drain: the jobs not yet started are skipped, the call returns once the copier no longer touches the caller's memory
+void copier_abort(Ctx* c, bool down, size_t n_jobs);
 
 struct Ctx {
     int device = -1;
@@ -152,7 +178,7 @@ struct Ctx {
     uint32_t aux_reserved = 0xffffffffu;  // CU reservation the aux streams were created with
     std::vector<hipEvent_t> aux_events;
     int ensure_aux(size_t n_events);
-    Copier* copier = nullptr;  // created on first use, joined by copier_stop (release_ctx)
+    Copier* copier[2] = {nullptr, nullptr};  // [0] uploads, [1] downloads; created on first use, joined by copier_stop (release_ctx)
     // multi-device engine, HALO2_HIP_GATHER=rccl: stage C also leaves the run's set sums in `gather` (device memory), from where
     // ncclAllGather takes them; gather_off counts the bytes left there by this call (SIZE_MAX / 2 and up: not one run, unusable)
     bool gather_want = false;

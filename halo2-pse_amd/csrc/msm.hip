@@ -1601,109 +1601,18 @@ void msm_set_stream(uint32_t chunks, double ratio, size_t min_n) {
     g_stream_min_n = min_n ? min_n : ((size_t)1 << 19);
 }
 
-// The copies are issued by a helper thread (one per device context): hipMemcpyAsync from pageable memory returns only when
+// The copies are issued by a helper thread (engine.h, copier_*): hipMemcpyAsync from pageable memory returns only when
 // its piece has left the host, and the thread that enqueues the kernels must not sit in it -- with one thread doing both, chunk
 // k + 1 started to cross PCIe only after chunk k's launches were queued and the sort of chunk k + 1 only a launch latency after
-// its copy had ended: no overlap was left (measured, rocprofv3 timeline of round 3).  The copier walks a job list; after each
-// job it records the job's event (if any) on its copy stream and bumps `done`; the enqueueing thread spins on `done` -- a
-// chunk is at most a few hundred microseconds away -- and then makes its stream wait on the event.
-struct CopyJob {
-    void* dst;
-    const void* src;
-    size_t bytes;
-    hipEvent_t ev;  // recorded on the copy stream after this job; nullptr: none
-};
-
-struct Copier {
-    std::thread th;
-    std::mutex m;
-    std::condition_variable cv;
-    std::vector<CopyJob> jobs;
-    hipStream_t stream = nullptr;
-    int device = 0;
-    bool has_work = false, quit = false;
-    std::atomic<size_t> done{0};
-    std::atomic<int> err{0};
-};
-
-static void copier_main(Copier* cp) {
-    (void)hipSetDevice(cp->device);
-    std::unique_lock<std::mutex> lk(cp->m);
-    for (;;) {
-        cp->cv.wait(lk, [&] { return cp->has_work || cp->quit; });
-        if (cp->quit) return;
-        cp->has_work = false;
-        std::vector<CopyJob> jobs;
-        jobs.swap(cp->jobs);
-        hipStream_t st = cp->stream;
-        lk.unlock();
-        for (size_t i = 0; i < jobs.size(); i++) {
-            if (!cp->err.load(std::memory_order_relaxed)) {
-                hipError_t e = hipMemcpyAsync(jobs[i].dst, jobs[i].src, jobs[i].bytes, hipMemcpyHostToDevice, st);
-                if (e == hipSuccess && jobs[i].ev) e = hipEventRecord(jobs[i].ev, st);
-                if (e != hipSuccess) cp->err.store((int)e);
-            }
-            cp->done.fetch_add(1, std::memory_order_release);
-        }
-        lk.lock();
-    }
-}
-
-// hand `jobs` to c's copier (started on first use); the caller then follows `done` with copier_wait
-static int copier_submit(Ctx* c, std::vector<CopyJob>& jobs, hipStream_t stream) {
-    if (!c->copier) {
-        c->copier = new Copier();
-        c->copier->device = c->device;
-        c->copier->th = std::thread(copier_main, c->copier);
-    }
-    Copier* cp = c->copier;
-    std::lock_guard<std::mutex> lk(cp->m);
-    cp->jobs.swap(jobs);
-    cp->stream = stream;
-    cp->done.store(0);
-    cp->err.store(0);
-    cp->has_work = true;
-    cp->cv.notify_all();
-    return 0;
-}
-
-// block until the first n_jobs jobs of the current list have been issued (for pageable sources: have left the host)
-static int copier_wait(Ctx* c, size_t n_jobs) {
-    Copier* cp = c->copier;
-    uint32_t spins = 0;
-    while (cp->done.load(std::memory_order_acquire) < n_jobs)
-        if (++spins > 2000) std::this_thread::yield();
-    if (int e = cp->err.load()) {
-        set_error("msm: host-to-device copy of a streamed chunk failed: %s", hipGetErrorString((hipError_t)e));
-        return 2;
-    }
-    return 0;
-}
-
-void copier_stop(Ctx* c) {
-    Copier* cp = c->copier;
-    if (!cp) return;
-    {
-        std::lock_guard<std::mutex> lk(cp->m);
-        cp->quit = true;
-        cp->cv.notify_all();
-    }
-    cp->th.join();
-    delete cp;
-    c->copier = nullptr;
-}
+// its copy had ended: no overlap was left (measured, rocprofv3 timeline of round 3).  The enqueueing thread follows the copier's
+// progress counter -- a chunk is at most a few hundred microseconds away -- and then makes its stream wait on the job's event.
 
 // a streamed run owns the copier until every job has been issued: an early error return must not leave it reading the caller's
 // arrays (or this frame's events) behind the call's back
 struct CopierDrain {
     Ctx* c;
     size_t n_jobs;
-    ~CopierDrain() {
-        Copier* cp = c->copier;
-        if (!cp || cp->done.load(std::memory_order_acquire) >= n_jobs) return;
-        if (!cp->err.load()) cp->err.store((int)hipErrorUnknown);  // the jobs not yet started are skipped
-        while (cp->done.load(std::memory_order_acquire) < n_jobs) std::this_thread::yield();
-    }
+    ~CopierDrain() { copier_abort(c, false, n_jobs); }
 };
 
 // units cut into at most K pieces with sizes ~ r^-k, each a multiple of `quantum` (the last takes the remainder)
@@ -1784,17 +1693,18 @@ static int msm_stream_host(Ctx* c, const Fe* h_scalars, const Affine* h_bases, c
     size_t o = 0;
     std::vector<CopyJob> jobs;
     for (size_t k = 0; k < K; k++) {
-        if (h_bases) jobs.push_back(CopyJob{d_bs + o, h_bases + o, sz[k] * sizeof(Affine), nullptr});
-        jobs.push_back(CopyJob{d_sc + o, h_scalars + o, sz[k] * sizeof(Fe), ev[1 + k]});
+        if (h_bases) jobs.push_back(CopyJob{d_bs + o, h_bases + o, sz[k] * sizeof(Affine), nullptr, nullptr, false});
+        jobs.push_back(CopyJob{d_sc + o, h_scalars + o, sz[k] * sizeof(Fe), ev[1 + k], nullptr, false});
         o += sz[k];
     }
     const size_t per_chunk = h_bases ? 2 : 1;
     H2_CHECK(hipStreamSynchronize(s));  // the copies start now: whatever was queued ahead of this call has to be done with the buffers
-    if ((rc = copier_submit(c, jobs, cs))) return rc;
+    if ((rc = copier_begin(c, false, cs))) return rc;
     CopierDrain drain{c, K * per_chunk};
+    if ((rc = copier_push(c, false, jobs))) return rc;
     o = 0;
     for (size_t k = 0; k < K; k++) {
-        if ((rc = copier_wait(c, (k + 1) * per_chunk))) return rc;
+        if ((rc = copier_wait(c, false, (k + 1) * per_chunk))) return rc;
         H2_CHECK(hipStreamWaitEvent(s, ev[1 + k], 0));
         const Fe* sc = d_sc + o;
         if ((rc = msm_stage_a(c, Lk[k], base, &sc, tab, s))) return rc;
@@ -1849,18 +1759,19 @@ static int msm_fused_groups_host(Ctx* c, const Fe* const* h_scalars, const Affin
     for (size_t g = 0; g < G; g++) {
         for (size_t j = j0; j < j0 + groups[g]; j++) {
             Fe* dst = (Fe*)c->msm_scalars[0].p + j * n;
-            jobs.push_back(CopyJob{dst, h_scalars[j], n * sizeof(Fe), j + 1 == j0 + groups[g] ? ev[1 + 3 * g] : nullptr});
+            jobs.push_back(CopyJob{dst, h_scalars[j], n * sizeof(Fe), j + 1 == j0 + groups[g] ? ev[1 + 3 * g] : nullptr, nullptr, false});
             list[j] = dst;
         }
         j0 += groups[g];
     }
     H2_CHECK(hipStreamSynchronize(s));  // as in msm_stream_host
-    if ((rc = copier_submit(c, jobs, cs))) return rc;
+    if ((rc = copier_begin(c, false, cs))) return rc;
     CopierDrain drain{c, count};
+    if ((rc = copier_push(c, false, jobs))) return rc;
     j0 = 0;
     for (size_t g = 0; g < G; g++) {
         const size_t cnt = groups[g];
-        if ((rc = copier_wait(c, j0 + cnt))) return rc;
+        if ((rc = copier_wait(c, false, j0 + cnt))) return rc;
         char* base = (char*)c->msm_slot[g & 1].p;
         H2_CHECK(hipStreamWaitEvent(sa, ev[1 + 3 * g], 0));
         if (g >= 2) H2_CHECK(hipStreamWaitEvent(sa, ev[3 + 3 * (g - 2)], 0));  // the slot is free once group g - 2 is reduced
@@ -1921,7 +1832,7 @@ int msm_batch_device(Ctx* c, const Fe* const* d_scalars, bool scalars_on_host, c
             tsub = &sub;
             points = sub.table;
         }
-        const bool stream = scalars_on_host && g_stream_chunks > 1;
+        const bool stream = scalars_on_host && g_stream_chunks > 1 && copier_ready(c, false);
         if (stream && count == 1 && m >= g_stream_min_n) {  // a lone host-resident MSM: chunks stream in under the work
             int rc = msm_stream_host(c, ptrs[0], h_bases ? h_bases + o : nullptr, points, tsub, m, part.data(), s);
             if (rc) return rc;

@@ -206,6 +206,20 @@ int h2hip_coeff_to_extended_bn254_fr_batch_device(void* const* d_a, size_t count
                                                   const uint64_t extended_omega[4], const uint64_t g_coset[4],
                                                   const uint64_t g_coset_inv[4], void* stream);
 
+/* ---- batched transforms on HOST columns: what the prover has when its polynomials are `Vec<F>`s (plonk/prover.rs:476-490 converts
+ * every advice column with lagrange_to_coeff; plonk/evaluation.rs:306-323 extends every advice / instance column with coeff_to_extended).
+ * `a` / `out` are host arrays of `count` host pointers; semantics per column are those of the unbatched host entry points.  The columns
+ * run as a three-stage pipeline -- column i + 1 crosses PCIe upwards and column i - 1 downwards while column i is transformed -- so a
+ * column costs max(upload, transform, download) instead of their sum (2^22: 5.4 ms one call each).  With several devices the columns
+ * are dealt to them in contiguous shares, each share over its own PCIe link (NTT replicas; no column crosses xGMI).  Blocking. */
+int h2hip_ntt_bn254_fr_batch(uint64_t* const* a, size_t count, const uint64_t omega[4], uint32_t log_n);
+int h2hip_ifft_bn254_fr_batch(uint64_t* const* a, size_t count, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4]);
+/* a[i]: 2^k coefficients in, out[i]: 2^extended_k evaluations out (a[i] and out[i] may not overlap unless equal) */
+int h2hip_coeff_to_extended_bn254_fr_batch(const uint64_t* const* a, uint32_t k, uint64_t* const* out, size_t count, uint32_t extended_k,
+                                           const uint64_t extended_omega[4], const uint64_t g_coset[4], const uint64_t g_coset_inv[4]);
+int h2hip_extended_to_coeff_bn254_fr_batch(uint64_t* const* a, size_t count, uint32_t extended_k, const uint64_t extended_omega_inv[4],
+                                           const uint64_t extended_ifft_divisor[4], const uint64_t g_coset[4], const uint64_t g_coset_inv[4]);
+
 /* ---- g_to_lagrange: arithmetic.rs:277-301 (best_fft with G = G1, then 1/n and batch_normalize); called by
  * ParamsKZG::downsize, poly/kzg/commitment.rs:267-275.  g_xy: 2^k affine points (the coefficient-basis SRS, possibly
  * truncated); g_lagrange_xy: 2^k affine points out.  k <= 28.  Input and output may not overlap. */

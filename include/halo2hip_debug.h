@@ -57,6 +57,9 @@ int h2hip_debug_set_ntt_batch_bytes(uint64_t bytes);
 int h2hip_debug_set_ntt_two_pass_batch_wgs(uint64_t v);
 /* three-pass plan: strided passes up to 2^v points read their inter-pass twiddles from a per-domain table (0 = default 20) */
 int h2hip_debug_set_ntt_full_max_log_m(uint32_t v);
+/* host-pointer batched transforms: device bytes one pipelined run may hold (0 = default 4 GB; smaller forces several runs) and the
+ * size below which columns are grouped per pipeline step (0 = default 2 MB) */
+int h2hip_debug_set_ntt_host_batch(uint64_t run_bytes, uint64_t group_bytes);
 /* two-pass plan: log2 columns per workgroup (-1 = default) */
 int h2hip_debug_set_ntt_two_pass_log_j(int v);
 /* evaluate_h: programs needing more slots than v use the global-workspace form of the kernels (default 256) */

@@ -49,15 +49,23 @@ def run(h2, cpu=True, fixed_base=True, scalars="dense"):
     ext = [torch.zeros((1 << ek, 4), dtype=torch.int64, device="cuda") for _ in range(10)]
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
-    def timed(f, reps=3):
+    rep_log = {}
+
+    def timed(f, reps=5, name=None):
+        """median of `reps` repetitions, each between its own pair of events (round 3 took the mean of three between ONE pair: a single
+        stall owned the figure and nothing showed it was one); the list rides along in the result"""
         f()
         torch.cuda.synchronize()
-        ev[0].record()
+        ts = []
         for _ in range(reps):
+            ev[0].record()
             f()
-        ev[1].record()
-        torch.cuda.synchronize()
-        return ev[0].elapsed_time(ev[1]) / reps
+            ev[1].record()
+            torch.cuda.synchronize()
+            ts.append(ev[0].elapsed_time(ev[1]))
+        if name:
+            rep_log[name] = [round(t, 4) for t in ts]
+        return sorted(ts)[len(ts) // 2]
 
     def fill_ext():
         for e, c in zip(ext, lag):
@@ -89,8 +97,8 @@ def run(h2, cpu=True, fixed_base=True, scalars="dense"):
         h2.coeff_to_extended_batch_device(ext, k, ek, d.extended_omega, d.g_coset, d.g_coset_inv)
         h2.extended_to_coeff_device(ext[0], ek, d.extended_omega_inv, d.extended_ifft_divisor, d.g_coset, d.g_coset_inv)
 
-    out = {"k": k, "extended_k": ek, "fixed_base": fixed_base, "scalars": scalars, "single_ms": timed(single), "batched_ms": timed(batched),
-           "fill_ext_ms": timed(fill_ext) + timed(restore),
+    out = {"k": k, "extended_k": ek, "fixed_base": fixed_base, "scalars": scalars, "single_ms": timed(single, name="single"),
+           "batched_ms": timed(batched, name="batched"), "fill_ext_ms": timed(fill_ext) + timed(restore), "reps_ms": rep_log, "stat": "median of 5",
            "calls": "16 MSMs of 2^17 (10 commit_lagrange + 6 commit), 10 iNTTs, 10 coset NTTs 2^17 -> 2^19, one inverse coset NTT of 2^19"}
     if fixed_base:
         h2.bases_unpin_device(g)
@@ -116,9 +124,104 @@ def run(h2, cpu=True, fixed_base=True, scalars="dense"):
     return out
 
 
+def run_host(h2, scalars="dense", reps=5):
+    """The same 37 calls with HOST columns (numpy arrays = pageable caller memory, as a Rust prover's Vec<F>), PCIe included:
+    `single_ms` one C-ABI call per reference call (what patches 0001 + 0002 yield), `batched_ms` through the host batch entry points
+    (h2hip_msm_bn254_batch, h2hip_{ifft,coeff_to_extended}_bn254_fr_batch: patches 0004 + 0005).  g / g_lagrange are pinned host arrays."""
+    import ctypes
+    import numpy as np
+    k = 17
+    n = 1 << k
+    d = h2.EvaluationDomain.new(4, k)
+    ek = d.extended_k
+    L = h2.lib()
+    g = h2.to_numpy_u64(h2.gen_points_device(0xABCD, n)).copy()
+    gl = h2.to_numpy_u64(h2.gen_points_device(0xABCE, n)).copy()
+    h2.bases_pin(g)
+    h2.bases_pin(gl)
+    lag_d = [h2.gen_scalars_device(600 + i, n) for i in range(10)]
+    if scalars == "prover-like":
+        lag_d = [prover_like(h2, c, 900 + i) for i, c in enumerate(lag_d)]
+    lag0 = [h2.to_numpy_u64(c).copy() for c in lag_d]
+    del lag_d
+    lag = [c.copy() for c in lag0]
+    ext = [np.zeros((1 << ek, 4), dtype=np.uint64) for _ in range(10)]
+    out1 = np.zeros(12, dtype=np.uint64)
+    out10 = np.zeros((10, 12), dtype=np.uint64)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    ptrs = lambda arrs: (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])  # noqa: E731
+    u32, sz = ctypes.c_uint32, ctypes.c_size_t
+
+    def ok(rc):
+        if rc:
+            raise RuntimeError(L.h2hip_last_error().decode())
+
+    def restore():
+        for c, c0 in zip(lag, lag0):
+            np.copyto(c, c0)
+
+    def single():
+        for c in lag:
+            ok(L.h2hip_msm_bn254(P(c), P(gl), sz(n), P(out1)))
+        for c in lag:
+            ok(L.h2hip_ifft_bn254_fr(P(c), P(d.omega_inv), u32(k), P(d.ifft_divisor)))
+        for c in lag[:6]:
+            ok(L.h2hip_msm_bn254(P(c), P(g), sz(n), P(out1)))
+        for c, e in zip(lag, ext):
+            ok(L.h2hip_coeff_to_extended_bn254_fr(P(c), u32(k), P(e), u32(ek), P(d.extended_omega), P(d.g_coset), P(d.g_coset_inv)))
+        ok(L.h2hip_extended_to_coeff_bn254_fr(P(ext[0]), u32(ek), P(d.extended_omega_inv), P(d.extended_ifft_divisor), P(d.g_coset), P(d.g_coset_inv)))
+
+    def batched():
+        ok(L.h2hip_msm_bn254_batch(ptrs(lag), P(gl), sz(n), sz(10), P(out10)))
+        ok(L.h2hip_ifft_bn254_fr_batch(ptrs(lag), sz(10), P(d.omega_inv), u32(k), P(d.ifft_divisor)))
+        ok(L.h2hip_msm_bn254_batch(ptrs(lag[:6]), P(g), sz(n), sz(6), P(out10)))
+        ok(L.h2hip_coeff_to_extended_bn254_fr_batch(ptrs(lag), u32(k), ptrs(ext), sz(10), u32(ek), P(d.extended_omega), P(d.g_coset), P(d.g_coset_inv)))
+        ok(L.h2hip_extended_to_coeff_bn254_fr(P(ext[0]), u32(ek), P(d.extended_omega_inv), P(d.extended_ifft_divisor), P(d.g_coset), P(d.g_coset_inv)))
+
+    legs = {}
+
+    def timed(f, name):
+        restore()
+        f()
+        ts = []
+        for _ in range(reps):
+            restore()  # outside the clock: the reference's lagrange_to_coeff consumes its Vec, there is no copy to charge
+            t0 = time.perf_counter()
+            f()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        legs[name] = [round(t, 4) for t in ts]
+        return sorted(ts)[len(ts) // 2]
+
+    try:
+        res = {"k": k, "extended_k": ek, "scalars": scalars, "single_ms": timed(single, "single"), "batched_ms": timed(batched, "batched"),
+               "reps_ms": legs, "stat": "median of %d, host clock around blocking calls" % reps,
+               "pcie_bytes": {"up": (16 + 10 + 10) * n * 32 + (32 << ek), "down": 10 * n * 32 + 11 * (32 << ek)},
+               "calls": "the 37 calls of trace_k17 on host columns (pageable numpy arrays), g / g_lagrange pinned host arrays"}
+        # where the batched time goes, call by call (one extra untimed pass)
+        parts = {}
+        restore()
+        for name, f in (("msm_batch_10", lambda: ok(L.h2hip_msm_bn254_batch(ptrs(lag), P(gl), sz(n), sz(10), P(out10)))),
+                        ("ifft_batch_10", lambda: ok(L.h2hip_ifft_bn254_fr_batch(ptrs(lag), sz(10), P(d.omega_inv), u32(k), P(d.ifft_divisor)))),
+                        ("msm_batch_6", lambda: ok(L.h2hip_msm_bn254_batch(ptrs(lag[:6]), P(g), sz(n), sz(6), P(out10)))),
+                        ("coeff_to_extended_batch_10", lambda: ok(L.h2hip_coeff_to_extended_bn254_fr_batch(ptrs(lag), u32(k), ptrs(ext), sz(10), u32(ek), P(d.extended_omega), P(d.g_coset), P(d.g_coset_inv)))),
+                        ("extended_to_coeff_1", lambda: ok(L.h2hip_extended_to_coeff_bn254_fr(P(ext[0]), u32(ek), P(d.extended_omega_inv), P(d.extended_ifft_divisor), P(d.g_coset), P(d.g_coset_inv))))):
+            f()
+            t0 = time.perf_counter()
+            f()
+            parts[name] = round((time.perf_counter() - t0) * 1e3, 4)
+        res["batched_parts_ms"] = parts
+        return res
+    finally:
+        h2.bases_unpin(g)
+        h2.bases_unpin(gl)
+
+
 def main():
     h2 = load_pkg()
     h2.init()
+    if "--host" in sys.argv:
+        print(json.dumps(run_host(h2, scalars="prover-like" if "--prover-like" in sys.argv else "dense")))
+        return
     print(json.dumps(run(h2, cpu="--no-cpu" not in sys.argv, fixed_base="--plain" not in sys.argv,
                          scalars="prover-like" if "--prover-like" in sys.argv else "dense")))
 
