@@ -192,7 +192,7 @@ def bases_unpin(bases):
     _check(lib().h2hip_bases_unpin(_p(bases)), "h2hip_bases_unpin")
 
 
-_device_pins = {}  # device address -> weakref.finalize of the tensor that was pinned
+_device_pins = {}  # device address -> weakref.finalize on the STORAGE of the tensor that was pinned
 
 
 def _unpin_address(addr):
@@ -204,9 +204,10 @@ def _unpin_address(addr):
 
 
 def bases_pin_device(d_bases, n=None):
-    """pin device-resident points (torch CUDA tensor): copies them and builds the fixed-base window table.  The tensor's
-    address is the cache key, so the entry is tied to the tensor's lifetime: when the tensor is dropped without
-    bases_unpin_device the entry goes with it (the library's own fingerprint check is the second line of defence)."""
+    """pin device-resident points (torch CUDA tensor): copies them and builds the fixed-base window table.  The buffer's
+    address is the cache key, so the entry is tied to the lifetime of the tensor's STORAGE (not of the tensor object: pinning
+    through a view or a temporary -- `t.view(-1)`, `t[:n]` -- must not unpin while `t` is alive): when the storage is freed
+    without bases_unpin_device the entry goes with it (the library's own fingerprint check is the second line of defence)."""
     import weakref
     n = d_bases.numel() * d_bases.element_size() // 64 if n is None else int(n)
     _check(lib().h2hip_bases_pin_device(_dptr(d_bases), ctypes.c_size_t(n), _stream()), "h2hip_bases_pin_device")
@@ -214,7 +215,9 @@ def bases_pin_device(d_bases, n=None):
     old = _device_pins.pop(addr, None)
     if old is not None:
         old.detach()
-    _device_pins[addr] = weakref.finalize(d_bases, _unpin_address, addr)
+    # torch keeps one Python wrapper per storage alive as long as the storage is (checked on this image: a finalizer attached to
+    # `t.view(-1).untyped_storage()` fires when the last tensor over the storage goes, not when the temporary view does)
+    _device_pins[addr] = weakref.finalize(d_bases.untyped_storage(), _unpin_address, addr)
 
 
 def bases_unpin_device(d_bases):

@@ -17,8 +17,12 @@
 #include "../../include/halo2hip_debug.h"
 #include "engine.h"
 
-// the optional lazy pin cache (further down, outside the namespace)
+// the optional lazy pin cache (further down, inside the extern "C" block: declared with that linkage here too, g++ insists)
+extern "C" {
 static void lazy_forget(const void* key);
+static void lazy_reset();
+static void lazy_pin_consider(const uint64_t* bases_xy, size_t n);
+}
 
 namespace h2 {
 
@@ -606,16 +610,21 @@ static int init_one(Ctx* c, int dev) {
 
 static void release_ctx(Ctx* c);
 
+static std::atomic<int> g_init_failed{0};  // an attempt found no usable GPU; lazy initialisation does not try again (ensure_init)
+
 static int do_init(const int* device_ids, int n_ids) {
     Ctx* c = ctx();
     std::unique_lock<std::shared_mutex> lk(g_engine_mu);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
         set_error("no usable HIP device (%s); libhalo2hip has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        g_init_failed.store(1, std::memory_order_release);
         return H2HIP_EDEVICE;
     }
-    read_config();
+    g_init_failed.store(0, std::memory_order_release);
+    if (!c->ready) read_config();  // a running engine keeps the configuration it started with: entry points read it under the shared lock
     // the device list: the caller's, else HALO2_HIP_DEVICES ("0,1,2,3"), else the calling thread's current device
     std::vector<int> ids;
     if (device_ids && n_ids > 0) {
@@ -682,6 +691,10 @@ static int do_init(const int* device_ids, int n_ids) {
 }
 
 int ensure_init() {
+    if (g_init_failed.load(std::memory_order_acquire)) {  // no usable GPU, found out once: the CPU-fallback path takes no lock and makes no HIP call
+        set_error("no usable HIP device (cached from the first attempt; h2hip_init or h2hip_shutdown retries); libhalo2hip has no CPU fallback");
+        return H2HIP_EDEVICE;
+    }
     {
         std::shared_lock<std::shared_mutex> lk(g_engine_mu);
         if (ctx()->ready) return 0;
@@ -1056,9 +1069,6 @@ static int msm_device_keyed(Ctx* c, const Fe* const* d_scalars, const Affine* d_
 
 using namespace h2;
 
-static void lazy_reset();
-static void lazy_pin_consider(const uint64_t* bases_xy, size_t n);
-
 extern "C" {
 
 int h2hip_init(const int* device_ids, int n_devices) { return do_init(device_ids, n_devices); }
@@ -1066,6 +1076,7 @@ int h2hip_init(const int* device_ids, int n_devices) { return do_init(device_ids
 void h2hip_shutdown(void) {
     Ctx* c = ctx();
     std::unique_lock<std::shared_mutex> lk(g_engine_mu);  // waits for every running entry point
+    g_init_failed.store(0, std::memory_order_release);     // the next call looks for a GPU again
     if (!c->ready) return;
     for (size_t i = 1; i < g_workers.size(); i++) {
         Worker* w = g_workers[i];
@@ -1103,13 +1114,17 @@ int h2hip_num_devices(void) {
     return ctx()->ready ? (int)g_devs.size() : 0;
 }
 
+// The shim asks these on every best_multiexp / best_fft, from rayon workers: the configuration is read under the engine lock
+// (h2hip_init may be rewriting it), and without a usable GPU they answer "never" from the cached failure -- no lock, no HIP call.
 size_t h2hip_msm_min_n(void) {
-    (void)ensure_init();
+    if (ensure_init()) return SIZE_MAX;
+    std::shared_lock<std::shared_mutex> lk(g_engine_mu);
     return g_cfg.msm_min_n;
 }
 
 uint32_t h2hip_ntt_min_log_n(void) {
-    (void)ensure_init();
+    if (ensure_init()) return UINT32_MAX;
+    std::shared_lock<std::shared_mutex> lk(g_engine_mu);
     return g_cfg.ntt_min_log_n;
 }
 
@@ -1493,7 +1508,8 @@ static void lazy_pin_consider(const uint64_t* bases_xy, size_t n) {
 }
 
 uint32_t h2hip_lazy_pin_after(void) {
-    (void)ensure_init();
+    if (ensure_init()) return 0;
+    std::shared_lock<std::shared_mutex> lk(g_engine_mu);
     return g_cfg.lazy_pin_after;
 }
 

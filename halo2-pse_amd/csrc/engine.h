@@ -56,13 +56,15 @@ struct TwiddleTable {
     Fu* lo = nullptr;  // omega^i, i < 2^lo_bits                                  (I-form limbs, fieldu.cuh)
     Fu* hi = nullptr;  // omega^(i << lo_bits), i < 2^(log_n - lo_bits) (at least 1 entry)
     uint32_t lo_bits = 0;
-    // two-pass plan (ntt.hip): the tile DFT's own twiddles w_R^i, i < R / 2, for R = 2^stage_s[t]
-    Fu* stage[2] = {nullptr, nullptr};
-    uint32_t stage_s[2] = {0, 0};
-    // the inter-pass twiddles of a pass as one table, when the budget allows (ntt.hip get_full_twiddles): slot 0 the two-pass plan's
-    // pass 1, slots 1..3 strided pass 0..2 of the other plan; tag = log_m << 8 | s
-    Fu* full[4] = {nullptr, nullptr, nullptr, nullptr};
-    uint32_t full_tag[4] = {0, 0, 0, 0};
+    // the tile DFT's own twiddles w_R^i, i < R / 2, for R = 2^s (ntt.hip get_stage_twiddles): one table per radix a plan has used on
+    // this domain.  Keyed by s, not by plan: a lone transform and a batch of the same domain take different plans (three passes /
+    // two), and until round 4 every switch freed and rebuilt the other plan's tables behind a device-wide synchronisation.
+    Fu* stage_of[13] = {};
+    // the inter-pass twiddles of a pass as one table, when the budget allows (ntt.hip get_full_twiddles); tag = layout << 31 |
+    // log_m << 8 | s (layout 1: the two-pass plan's pass 1).  Up to H2_TW_FULL tables per domain, none is ever replaced.
+#define H2_TW_FULL 8
+    Fu* full[H2_TW_FULL] = {};
+    uint32_t full_tag[H2_TW_FULL] = {};
     // `lo` times one constant (the 1/n of the inverse transform that uses this domain): a first pass that combines its inter-pass
     // twiddles from the two-level table then scales for free, and the last pass closes with the direct reduction (ntt.hip ntt_run)
     Fu* lo_scaled = nullptr;

@@ -455,9 +455,8 @@ void ntt_twiddles_free(Ctx* c) {
         TwiddleTable& t = kv.second;
         (void)hipFree(t.lo);
         (void)hipFree(t.hi);
-        if (t.stage[1] != t.stage[0]) (void)hipFree(t.stage[1]);
-        (void)hipFree(t.stage[0]);
-        for (int k = 0; k < 4; k++) (void)hipFree(t.full[k]);
+        for (int k = 0; k < 13; k++) (void)hipFree(t.stage_of[k]);
+        for (int k = 0; k < H2_TW_FULL; k++) (void)hipFree(t.full[k]);
         (void)hipFree(t.lo_scaled);
     }
     c->twiddles.clear();
@@ -546,7 +545,7 @@ int ntt_power_table(Ctx* c, const Fe& omega, uint32_t log_n, hipStream_t s, cons
     return 0;
 }
 
-// the two-pass plan's tile twiddles w_R^i (i < R / 2) for R = 2^s1 and 2^s2, built once per domain
+// the tile twiddles w_R^i (i < R / 2) for R = 2^s1 and 2^s2, each built once per domain and radix
 static int get_stage_twiddles(Ctx* c, const Fe& omega, uint32_t log_n, uint32_t s1, uint32_t s2, hipStream_t s, TwiddleTable* out) {
     TwiddleKey key;
     for (int i = 0; i < 8; i++) key.omega[i] = omega.l[i];
@@ -558,37 +557,31 @@ static int get_stage_twiddles(Ctx* c, const Fe& omega, uint32_t log_n, uint32_t 
     }
     TwiddleTable& t = it->second;
     const uint32_t want[2] = {s1, s2};
-    if (t.stage[0] && (t.stage_s[0] != s1 || t.stage_s[1] != s2)) {  // the plan changed under a tuning hook
-        H2_CHECK(hipDeviceSynchronize());
-        if (t.stage[1] != t.stage[0]) (void)hipFree(t.stage[1]);
-        (void)hipFree(t.stage[0]);
-        t.stage[0] = t.stage[1] = nullptr;
-    }
     for (int k = 0; k < 2; k++) {
-        if (t.stage[k]) continue;
-        if (k == 1 && want[1] == want[0]) {
-            t.stage[1] = t.stage[0];
-            t.stage_s[1] = want[1];
-            break;
+        if (want[k] < 1 || want[k] > 12) {
+            set_error("ntt: tile radix 2^%u out of range", want[k]);
+            return 1;
         }
+        if (t.stage_of[want[k]]) continue;
         const uint32_t cnt = 1u << (want[k] - 1);
         Fu* d = nullptr;
         H2_CHECK(hipMalloc((void**)&d, (size_t)cnt * sizeof(Fu)));
         hipLaunchKernelGGL(stage_twiddle_build_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, omega, log_n - want[k], cnt, d);
         H2_CHECK(hipGetLastError());
         H2_CHECK(hipStreamSynchronize(s));  // built once per domain; later calls may use another stream
-        t.stage[k] = d;
-        t.stage_s[k] = want[k];
+        t.stage_of[want[k]] = d;
     }
     *out = t;
     return 0;
 }
 
 // A pass's inter-pass twiddles as one table, built once per domain while the budget lasts: it replaces the multiplication that
-// combines the two-level table -- one of a pass's six or seven per element -- by a 36-byte read.  Slot 0: the two-pass plan's pass 1
-// (2^log_n entries [lo][k]: 38 MB at 2^20, 75 MB at 2^21).  Slots 1..3: strided pass t of the other plan (2^log_m entries [k][lo]).
-// `p` carries the two-level table, log_m and s.  Leaves the slot null when the budget is spent: the kernels fall back to tw_pow.
-static int get_full_twiddles(Ctx* c, const Fe& omega, const NttPass& p, int slot, hipStream_t s, TwiddleTable* out) {
+// combines the two-level table -- one of a pass's six or seven per element -- by a 36-byte read.  two_pass: the two-pass plan's
+// pass 1 (2^log_n entries [lo][k]: 38 MB at 2^20, 75 MB at 2^21); otherwise a strided pass of the other plan (2^log_m entries
+// [k][lo]).  `p` carries the two-level table, log_m and s.  *table stays null when the budget (or the domain's H2_TW_FULL slots)
+// is spent: the kernels fall back to tw_pow.
+static int get_full_twiddles(Ctx* c, const Fe& omega, const NttPass& p, bool two_pass, hipStream_t s, const Fu** table) {
+    *table = nullptr;
     TwiddleKey key;
     for (int i = 0; i < 8; i++) key.omega[i] = omega.l[i];
     key.log_n = p.log_n;
@@ -596,31 +589,32 @@ static int get_full_twiddles(Ctx* c, const Fe& omega, const NttPass& p, int slot
     if (it == c->twiddles.end()) return 0;
     TwiddleTable& t = it->second;
     const size_t bytes = sizeof(Fu) << p.log_m;
-    const uint32_t tag = (p.log_m << 8) | p.s;
-    if (t.full[slot] && t.full_tag[slot] != tag) {  // the plan changed under a tuning hook
-        H2_CHECK(hipDeviceSynchronize());
-        (void)hipFree(t.full[slot]);
-        t.full[slot] = nullptr;
-        c->tw_full_bytes -= sizeof(Fu) << (t.full_tag[slot] >> 8);
-    }
-    if (!t.full[slot] && c->tw_full_bytes + bytes <= g_ntt_full_budget) {
-        Fu* d = nullptr;
-        if (hipMalloc((void**)&d, bytes) == hipSuccess) {
-            const dim3 grid((uint32_t)((((uint64_t)1 << p.log_m) + 255) / 256));
-            if (slot == 0)
-                hipLaunchKernelGGL(full_twiddle_build_kernel, grid, dim3(256), 0, s, p, d);
-            else
-                hipLaunchKernelGGL(pass_twiddle_build_kernel, grid, dim3(256), 0, s, p, d);
-            H2_CHECK(hipGetLastError());
-            H2_CHECK(hipStreamSynchronize(s));
-            t.full[slot] = d;
-            t.full_tag[slot] = tag;
-            c->tw_full_bytes += bytes;
-        } else {
-            (void)hipGetLastError();  // no room: not an error, the two-level table still serves
+    const uint32_t tag = (two_pass ? 0x80000000u : 0u) | (p.log_m << 8) | p.s;
+    int free_slot = -1;
+    for (int k = 0; k < H2_TW_FULL; k++) {
+        if (t.full[k] && t.full_tag[k] == tag) {
+            *table = t.full[k];
+            return 0;
         }
+        if (!t.full[k] && free_slot < 0) free_slot = k;
     }
-    *out = t;
+    if (free_slot < 0 || c->tw_full_bytes + bytes > g_ntt_full_budget) return 0;
+    Fu* d = nullptr;
+    if (hipMalloc((void**)&d, bytes) != hipSuccess) {
+        (void)hipGetLastError();  // no room: not an error, the two-level table still serves
+        return 0;
+    }
+    const dim3 grid((uint32_t)((((uint64_t)1 << p.log_m) + 255) / 256));
+    if (two_pass)
+        hipLaunchKernelGGL(full_twiddle_build_kernel, grid, dim3(256), 0, s, p, d);
+    else
+        hipLaunchKernelGGL(pass_twiddle_build_kernel, grid, dim3(256), 0, s, p, d);
+    H2_CHECK(hipGetLastError());
+    H2_CHECK(hipStreamSynchronize(s));
+    t.full[free_slot] = d;
+    t.full_tag[free_slot] = tag;
+    c->tw_full_bytes += bytes;
+    *table = d;
     return 0;
 }
 
@@ -795,7 +789,8 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
         // up to 2^21 points the table (36 B per point), the data and the workspace share the 256 MB Infinity Cache: -6 %; at 2^22 they
         // no longer do and the table costs 7 % instead
         p.log_m = log_n;
-        if (log_n <= 21 && (rc = get_full_twiddles(c, omega, p, 0, s, &tw))) return rc;
+        const Fu* full0 = nullptr;
+        if (log_n <= 21 && g_ntt_full_budget && (rc = get_full_twiddles(c, omega, p, true, s, &full0))) return rc;
         p.log_j = 0;  // one column / block per workgroup, neighbours grouped per XCD (ntt2_strided_kernel); two columns one after the other: see there
         if (g_ntt2_log_j >= 0 && g_ntt2_log_j <= 3) p.log_j = (uint32_t)g_ntt2_log_j;
         for (int t = 0; t < 2; t++) {
@@ -806,8 +801,8 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
                 const uint32_t want = t == 0 ? 2u : (log_n <= 21 ? 1u : 0u);  // pass 1: four columns = one 128-byte line; pass 2: pairs while the transform stays in the Infinity Cache
                 p.xgroup = (p.log_j == 0 && log_grid >= 3 + want) ? want : 0;
             }
-            p.stage_tw = tw.stage[t];
-            p.tw_full = t == 0 && g_ntt_full_budget ? tw.full[0] : nullptr;  // a zero budget also sets existing tables aside
+            p.stage_tw = tw.stage_of[S[t]];
+            p.tw_full = t == 0 ? full0 : nullptr;  // (a zero budget also sets existing tables aside)
             if (t == 0 && !p.tw_full && p.out_scale == 2 && sc) {
                 // one output constant (the inverse's 1/n) and pass 1 combining its twiddles from the two-level table: the constant rides in a
                 // scaled copy of `lo`, and pass 2 closes with the direct reduction instead of the multiply
@@ -835,7 +830,7 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
     uint32_t log_m = log_n;
     for (int t = 0; t < P; t++) {
         p.s = S[t];
-        p.stage_tw = p.s == tw.stage_s[0] ? tw.stage[0] : tw.stage[1];
+        p.stage_tw = tw.stage_of[p.s];
         p.log_m = log_m;
         p.first = (t == 0);
         bool final = (t == P - 1);
@@ -856,9 +851,10 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
             // a table of up to 2^20 entries (38 MB) stays cache-resident next to the data: every strided pass but the first of a large transform
             p.tw_full = nullptr;
             p.tw_lo = tw.lo;  // (before a table is built from it: pass_twiddle_build_kernel reads p)
-            if (log_m <= g_ntt_full_max_log_m && t < 3) {
-                if ((rc = get_full_twiddles(c, omega, p, 1 + t, s, &tw))) return rc;
-                p.tw_full = g_ntt_full_budget ? tw.full[1 + t] : nullptr;
+            if (log_m <= g_ntt_full_max_log_m && g_ntt_full_budget) {
+                const Fu* full = nullptr;
+                if ((rc = get_full_twiddles(c, omega, p, false, s, &full))) return rc;
+                p.tw_full = full;
             }
             if (t == 0 && !p.tw_full && p.out_scale == 2 && sc) {  // as in the two-pass plan: the one output constant rides in the first pass's twiddles
                 const Fu* lo_s = nullptr;

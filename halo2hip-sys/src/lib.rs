@@ -23,7 +23,7 @@ use ff::{Field, PrimeField};
 use halo2curves::bn256::{Fr, G1Affine, G1};
 use halo2curves::CurveAffine;
 use std::any::TypeId;
-use std::sync::Once;
+use std::sync::atomic::{AtomicU8, Ordering};
 
 pub const H2HIP_OK: i32 = 0;
 pub const H2HIP_EINVAL: i32 = 1;
@@ -54,23 +54,28 @@ pub fn last_error() -> String {
 /// layout-defined view ("uncompressed, internal Montgomery representation", halo2_proofs/src/helpers.rs:13-19), so the
 /// in-memory bytes of a few values are compared with it.
 fn layout_ok() -> bool {
-    static CHECK: Once = Once::new();
-    static mut OK: bool = false;
-    CHECK.call_once(|| {
-        use halo2curves::serde::SerdeObject;
-        let mut ok = std::mem::size_of::<Fr>() == 32 && std::mem::size_of::<G1Affine>() == 64 && std::mem::size_of::<G1>() == 96;
-        if ok {
-            let raw_of = |p: *const u8, n: usize| unsafe { std::slice::from_raw_parts(p, n) }.to_vec();
-            let two = Fr::one() + Fr::one();
-            ok &= raw_of(&two as *const Fr as *const u8, 32) == two.to_raw_bytes();
-            let g = G1Affine::generator();
-            ok &= raw_of(&g as *const G1Affine as *const u8, 64) == g.to_raw_bytes();
-            let id = G1Affine::default();
-            ok &= raw_of(&id as *const G1Affine as *const u8, 64) == vec![0u8; 64];
-        }
-        unsafe { OK = ok };
-    });
-    unsafe { OK }
+    // 0 = not checked yet, 1 = ok, 2 = mismatch.  An atomic rather than `static mut` (a hard error under the 2024 edition's
+    // static_mut_refs lint) or OnceLock (Rust 1.70; the reference's toolchain pin is older).  Two threads may both run the check
+    // the first time; they store the same answer.
+    static STATE: AtomicU8 = AtomicU8::new(0);
+    match STATE.load(Ordering::Acquire) {
+        1 => return true,
+        2 => return false,
+        _ => {}
+    }
+    use halo2curves::serde::SerdeObject;
+    let mut ok = std::mem::size_of::<Fr>() == 32 && std::mem::size_of::<G1Affine>() == 64 && std::mem::size_of::<G1>() == 96;
+    if ok {
+        let raw_of = |p: *const u8, n: usize| unsafe { std::slice::from_raw_parts(p, n) }.to_vec();
+        let two = Fr::one() + Fr::one();
+        ok &= raw_of(&two as *const Fr as *const u8, 32) == two.to_raw_bytes();
+        let g = G1Affine::generator();
+        ok &= raw_of(&g as *const G1Affine as *const u8, 64) == g.to_raw_bytes();
+        let id = G1Affine::default();
+        ok &= raw_of(&id as *const G1Affine as *const u8, 64) == vec![0u8; 64];
+    }
+    STATE.store(if ok { 1 } else { 2 }, Ordering::Release);
+    ok
 }
 
 fn is<A: 'static, B: 'static>() -> bool {
@@ -111,17 +116,13 @@ pub fn try_multiexp_batch<C: CurveAffine>(columns: &[&[C::Scalar]], bases: &[C])
 /// `best_fft` on the GPU: true when the engine took the call (`a` then holds the transform).
 /// Parity is defined for `omega` of exact order 2^log_n (every in-crate caller); anything else keeps the CPU body.
 pub fn try_fft<G: 'static, S: 'static>(a: &mut [G], omega: &S, log_n: u32) -> bool {
-    if !is::<G, Fr>() || !is::<S, Fr>() || log_n == 0 || log_n > Fr::S || a.len() != 1usize << log_n {
+    if log_n >= usize::BITS || a.len() != 1usize << log_n {
         return false;
     }
-    if log_n < unsafe { ffi::h2hip_ntt_min_log_n() } || !layout_ok() {
-        return false;
+    match fft_guards::<G, S>(omega, log_n) {
+        Some(w) => unsafe { ffi::h2hip_ntt_bn254_fr(a.as_mut_ptr() as *mut u64, w as *const Fr as *const u64, log_n) == 0 },
+        None => false,
     }
-    let w: &Fr = unsafe { &*(omega as *const S as *const Fr) };
-    if w.pow_vartime(&[1u64 << (log_n - 1)]) != -Fr::one() {
-        return false;
-    }
-    unsafe { ffi::h2hip_ntt_bn254_fr(a.as_mut_ptr() as *mut u64, w as *const Fr as *const u64, log_n) == 0 }
 }
 
 /// Keep `bases` (a `ParamsKZG`'s `g` or `g_lagrange`) on the GPU with its fixed-base window table until `unpin_bases`.
@@ -153,35 +154,92 @@ pub fn try_g_to_lagrange<C: CurveAffine>(g: &[C], k: u32) -> Option<Vec<C>> {
     Some(out)
 }
 
+/// Whether the engine takes a transform of 2^log_n elements of `G` at all (callers that would allocate for the engine ask first).
+pub fn takes_fft<G: 'static>(log_n: u32) -> bool {
+    is::<G, Fr>() && log_n != 0 && log_n <= Fr::S && log_n >= unsafe { ffi::h2hip_ntt_min_log_n() } && layout_ok()
+}
+
+/// The guards `try_fft` applies, for every transform wrapper: G = S = bn256::Fr, 1 <= log_n <= Fr::S and at least the engine's
+/// threshold, and `omega` of exact order 2^log_n (the engine's parity is defined for nothing else; the C side rejects a
+/// non-reduced element but cannot know the order the caller meant).
+fn fft_guards<G: 'static, S: 'static>(omega: &S, log_n: u32) -> Option<&Fr> {
+    if !is::<S, Fr>() || !takes_fft::<G>(log_n) {
+        return None;
+    }
+    let w: &Fr = unsafe { &*(omega as *const S as *const Fr) };
+    if w.pow_vartime(&[1u64 << (log_n - 1)]) != -Fr::one() {
+        return None;
+    }
+    Some(w)
+}
+
+fn fr_ptr<S>(x: &S) -> *const u64 {
+    x as *const S as *const u64
+}
+
 /// `EvaluationDomain::ifft` (poly/domain.rs:353-361) in one device round trip: NTT with `omega_inv`, scaled by `divisor`.
 pub fn try_ifft<G: 'static, S: 'static>(a: &mut [G], omega_inv: &S, log_n: u32, divisor: &S) -> bool {
-    if !is::<G, Fr>() || !is::<S, Fr>() || a.len() != 1usize << log_n || log_n < unsafe { ffi::h2hip_ntt_min_log_n() } || !layout_ok() {
+    if log_n >= usize::BITS || a.len() != 1usize << log_n || fft_guards::<G, S>(omega_inv, log_n).is_none() {
         return false;
     }
-    unsafe {
-        ffi::h2hip_ifft_bn254_fr(a.as_mut_ptr() as *mut u64, omega_inv as *const S as *const u64, log_n, divisor as *const S as *const u64) == 0
+    unsafe { ffi::h2hip_ifft_bn254_fr(a.as_mut_ptr() as *mut u64, fr_ptr(omega_inv), log_n, fr_ptr(divisor)) == 0 }
+}
+
+/// `ifft` for several columns of one size in one call: upload i + 1, transform i and download i - 1 overlap (h2hip_ifft_bn254_fr_batch).
+pub fn try_ifft_batch<G: 'static, S: 'static>(columns: &mut [&mut [G]], omega_inv: &S, log_n: u32, divisor: &S) -> bool {
+    if columns.is_empty() || log_n >= usize::BITS || columns.iter().any(|c| c.len() != 1usize << log_n) || fft_guards::<G, S>(omega_inv, log_n).is_none() {
+        return false;
     }
+    let ptrs: Vec<*mut u64> = columns.iter_mut().map(|c| c.as_mut_ptr() as *mut u64).collect();
+    unsafe { ffi::h2hip_ifft_bn254_fr_batch(ptrs.as_ptr(), ptrs.len(), fr_ptr(omega_inv), log_n, fr_ptr(divisor)) == 0 }
 }
 
 /// `EvaluationDomain::coeff_to_extended` (poly/domain.rs:240-254): zero-pad, distribute powers of zeta, extended NTT.
 /// `a` holds 2^k coefficients, `out` receives 2^extended_k evaluations.
-pub fn try_coeff_to_extended<S: 'static>(a: &[S], k: u32, out: &mut [S], extended_k: u32, extended_omega: &S, g_coset: &S, g_coset_inv: &S) -> bool {
-    if !is::<S, Fr>() || a.len() != 1usize << k || out.len() != 1usize << extended_k || !layout_ok() {
+pub fn try_coeff_to_extended<G: 'static, S: 'static>(a: &[G], k: u32, out: &mut [G], extended_k: u32, extended_omega: &S, g_coset: &S, g_coset_inv: &S) -> bool {
+    if k > extended_k || extended_k >= usize::BITS || a.len() != 1usize << k || out.len() != 1usize << extended_k {
         return false;
     }
-    let p = |x: &S| x as *const S as *const u64;
+    if fft_guards::<G, S>(extended_omega, extended_k).is_none() {
+        return false;
+    }
     unsafe {
-        ffi::h2hip_coeff_to_extended_bn254_fr(a.as_ptr() as *const u64, k, out.as_mut_ptr() as *mut u64, extended_k, p(extended_omega), p(g_coset), p(g_coset_inv)) == 0
+        ffi::h2hip_coeff_to_extended_bn254_fr(a.as_ptr() as *const u64, k, out.as_mut_ptr() as *mut u64, extended_k, fr_ptr(extended_omega), fr_ptr(g_coset), fr_ptr(g_coset_inv)) == 0
+    }
+}
+
+/// The same in place, as the reference does it: `a` has been resized to 2^extended_k elements, of which the first 2^k are the
+/// coefficients (the engine reads only those and writes all 2^extended_k).
+pub fn try_coeff_to_extended_in_place<G: 'static, S: 'static>(a: &mut [G], k: u32, extended_k: u32, extended_omega: &S, g_coset: &S, g_coset_inv: &S) -> bool {
+    if k > extended_k || extended_k >= usize::BITS || a.len() != 1usize << extended_k || fft_guards::<G, S>(extended_omega, extended_k).is_none() {
+        return false;
+    }
+    let p = a.as_mut_ptr() as *mut u64;
+    unsafe { ffi::h2hip_coeff_to_extended_bn254_fr(p as *const u64, k, p, extended_k, fr_ptr(extended_omega), fr_ptr(g_coset), fr_ptr(g_coset_inv)) == 0 }
+}
+
+/// `coeff_to_extended` for several polynomials in one pipelined call (plonk/evaluation.rs:306-323 extends every advice and
+/// instance column): `a[i]` holds 2^k coefficients, `out[i]` receives 2^extended_k evaluations.
+pub fn try_coeff_to_extended_batch<G: 'static, S: 'static>(a: &[&[G]], k: u32, out: &mut [&mut [G]], extended_k: u32, extended_omega: &S, g_coset: &S, g_coset_inv: &S) -> bool {
+    if a.is_empty() || a.len() != out.len() || k > extended_k || extended_k >= usize::BITS {
+        return false;
+    }
+    if a.iter().any(|c| c.len() != 1usize << k) || out.iter().any(|c| c.len() != 1usize << extended_k) || fft_guards::<G, S>(extended_omega, extended_k).is_none() {
+        return false;
+    }
+    let ins: Vec<*const u64> = a.iter().map(|c| c.as_ptr() as *const u64).collect();
+    let outs: Vec<*mut u64> = out.iter_mut().map(|c| c.as_mut_ptr() as *mut u64).collect();
+    unsafe {
+        ffi::h2hip_coeff_to_extended_bn254_fr_batch(ins.as_ptr(), k, outs.as_ptr(), ins.len(), extended_k, fr_ptr(extended_omega), fr_ptr(g_coset), fr_ptr(g_coset_inv)) == 0
     }
 }
 
 /// `EvaluationDomain::extended_to_coeff` (poly/domain.rs:281-303) before its `truncate`.
-pub fn try_extended_to_coeff<S: 'static>(a: &mut [S], extended_k: u32, extended_omega_inv: &S, extended_ifft_divisor: &S, g_coset: &S, g_coset_inv: &S) -> bool {
-    if !is::<S, Fr>() || a.len() != 1usize << extended_k || !layout_ok() {
+pub fn try_extended_to_coeff<G: 'static, S: 'static>(a: &mut [G], extended_k: u32, extended_omega_inv: &S, extended_ifft_divisor: &S, g_coset: &S, g_coset_inv: &S) -> bool {
+    if extended_k >= usize::BITS || a.len() != 1usize << extended_k || fft_guards::<G, S>(extended_omega_inv, extended_k).is_none() {
         return false;
     }
-    let p = |x: &S| x as *const S as *const u64;
     unsafe {
-        ffi::h2hip_extended_to_coeff_bn254_fr(a.as_mut_ptr() as *mut u64, extended_k, p(extended_omega_inv), p(extended_ifft_divisor), p(g_coset), p(g_coset_inv)) == 0
+        ffi::h2hip_extended_to_coeff_bn254_fr(a.as_mut_ptr() as *mut u64, extended_k, fr_ptr(extended_omega_inv), fr_ptr(extended_ifft_divisor), fr_ptr(g_coset), fr_ptr(g_coset_inv)) == 0
     }
 }

@@ -118,14 +118,15 @@ def test_crate_sources_are_complete():
 @pytest.mark.skipif(not os.path.isdir(REF) or shutil.which("patch") is None, reason="needs the reference tree and patch(1)")
 def test_patches_apply_to_the_reference(tmp_path):
     patches = sorted(f for f in os.listdir(os.path.join(ROOT, "patches")) if f.endswith(".patch"))
-    assert len(patches) >= 3
+    assert len(patches) >= 5
     touched = set()
     for p in patches:
         for line in open(os.path.join(ROOT, "patches", p)):
             if line.startswith("+++ b/"):
                 touched.add(line[6:].strip())
     assert {"halo2_proofs/src/arithmetic.rs", "halo2_proofs/src/poly/kzg/commitment.rs", "halo2_proofs/src/plonk/evaluation.rs",
-            "halo2_proofs/Cargo.toml"} <= touched
+            "halo2_proofs/Cargo.toml", "halo2_proofs/src/poly/domain.rs", "halo2_proofs/src/plonk/prover.rs",
+            "halo2_proofs/src/poly/commitment.rs", "halo2_proofs/src/plonk/vanishing/prover.rs"} <= touched
     for rel in touched:  # a scratch copy of just those files (nothing of the reference enters the repository)
         dst = tmp_path / rel
         dst.parent.mkdir(parents=True, exist_ok=True)
@@ -141,6 +142,22 @@ def test_patches_apply_to_the_reference(tmp_path):
     assert "assert_eq!(coeffs.len(), bases.len());" in arith[i + 1] and "halo2hip_sys::try_multiexp::<C>(coeffs, bases)" in arith[i + 2]
     j = next(k for k, ln in enumerate(arith) if "assert_eq!(n, 1 << log_n);" in ln)
     assert "halo2hip_sys::try_fft(a, &omega, log_n)" in arith[j + 1]
+    # 0004: the domain conversions try the fused engine calls first, and the two places that convert columns back to back batch them
+    dom = (tmp_path / "halo2_proofs/src/poly/domain.rs").read_text()
+    for call in ("halo2hip_sys::try_ifft(a, &omega_inv, log_n, &divisor)", "halo2hip_sys::try_coeff_to_extended_in_place(", "halo2hip_sys::try_extended_to_coeff(",
+                 "halo2hip_sys::try_ifft_batch(", "halo2hip_sys::try_coeff_to_extended_batch(", "pub fn lagrange_to_coeff_batch(", "pub fn coeff_to_extended_batch("):
+        assert call in dom, call
+    prover = (tmp_path / "halo2_proofs/src/plonk/prover.rs").read_text()
+    assert "domain.lagrange_to_coeff_batch(advice_polys)" in prover and ".map(|poly| domain.lagrange_to_coeff(poly))" not in prover
+    evaluation = (tmp_path / "halo2_proofs/src/plonk/evaluation.rs").read_text()
+    assert evaluation.count("domain.coeff_to_extended_batch(") == 2 and "domain.coeff_to_extended(poly.clone())" not in evaluation
+    # 0005: the back-to-back commits go through the batch methods, which ParamsKZG overrides with try_multiexp_batch
+    assert "params.commit_lagrange_batch(&advice_values, &blinds)" in prover and "params.commit_lagrange(poly, *blind)" not in prover
+    assert "params.commit_batch(&h_pieces, &h_blinds)" in (tmp_path / "halo2_proofs/src/plonk/vanishing/prover.rs").read_text()
+    kzg = (tmp_path / "halo2_proofs/src/poly/kzg/commitment.rs").read_text()
+    assert kzg.count("halo2hip_sys::try_multiexp_batch::<E::G1Affine>(") == 2
+    trait = (tmp_path / "halo2_proofs/src/poly/commitment.rs").read_text()
+    assert "fn commit_lagrange_batch(" in trait and "fn commit_batch(" in trait
     # every halo2hip_sys item the patches call exists in the crate
     called = set()
     for p in patches:

@@ -88,6 +88,25 @@ def test_host_code_under_asan_ubsan(tmp_path):
         assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
 
 
+def test_engine_host_logic_under_tsan(tmp_path):
+    """the multi-device host logic of csrc/api.hip -- per-context locks under the shared engine lock, the
+    single-slot hand-off to the per-device Worker threads, the copier threads of the host-pointer batched transforms, init /
+    shutdown racing with callers, the cached no-GPU state -- never ran on two distinct GPUs.  Here api.hip is compiled as plain
+    C++ against a stub HIP runtime with two fake devices (tests/cpp/hipstub) and driven from a dozen threads under
+    ThreadSanitizer (tests/cpp/test_engine_tsan.cpp); TSan turns any report into a non-zero exit."""
+    csrc = os.path.join(ROOT, "halo2-pse_amd", "csrc")
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    exe = str(tmp_path / "test_engine_tsan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-Wno-unknown-pragmas", "-I" + os.path.join(cpp, "hipstub"), "-I" + csrc,
+                           "-x", "c++", os.path.join(csrc, "api.hip"), os.path.join(cpp, "engine_stubs.cpp"), os.path.join(cpp, "test_engine_tsan.cpp"),
+                           "-o", exe, "-lpthread", "-ldl"])
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66 second_deadlock_stack=1")
+    env.pop("H2_STUB_DEVICES", None)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "engine host logic under tsan: ok" in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
+
+
 def test_bench_spawns_its_ranks_when_started_bare():
     """`python bench.py --gpus 2` with no WORLD_SIZE must start two ranks itself (the driver's launch shape) instead of
     exiting with a usage error.  There is no GPU here, so both ranks stop with the no-GPU message and the parent hands the

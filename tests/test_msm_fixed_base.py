@@ -217,13 +217,15 @@ def test_device_pinned_cache_detects_a_reused_address(h2, oracle):
 
 
 def test_device_pin_follows_the_tensor_lifetime(h2):
-    """the Python wrapper ties the entry to the tensor (weakref.finalize): dropping the tensor unpins"""
+    """the Python wrapper ties the entry to the tensor's storage (weakref.finalize): dropping the last tensor over it unpins,
+    dropping a temporary view the pin went through does not"""
     import ctypes
     import gc
     dp = h2.gen_points_device(0x5EED0002, 1 << 10)
-    h2.bases_pin_device(dp)
+    h2.bases_pin_device(dp.view(-1))  # pinned through a temporary view, collected at once
     addr = dp.data_ptr()
-    assert addr in h2._device_pins
+    gc.collect()
+    assert addr in h2._device_pins and h2.bases_pinned_info(dp)[0] == 1 << 10
     del dp
     gc.collect()
     assert addr not in h2._device_pins
