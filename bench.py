@@ -43,6 +43,10 @@ MSM_BYTES_PER_PAIR = 96  # 32 B scalar + 64 B affine point, read once (SURVEY.md
 NTT_BYTES_PER_ELEM = 64  # one 32 B read + one 32 B write per transform
 FIELD_MUL_PER_BUCKET_ADD = 9.2  # XYZZ mixed add: 7 products + 2 squares + one two-product single-reduction form (csrc/ecu.cuh)
 FIELD_MUL_PEAK_G = 179.0  # measured peak of csrc/fieldu.cuh's multiplier on MI355X, G multiplies/s (tools/mul_rate.hip)
+# Fr multiplications per element of one transform: (log2 n) / 2 butterfly products, plus per pass boundary one to apply the
+# inter-pass twiddle and -- where it is combined from the two-level table instead of read from a per-domain table -- one to combine it;
+# the closing reduction is not a multiplication.  2^22 on two passes: 11 + 2 = 13; 2^24 on three: 12 + 2.5 (one boundary reads a table) = 14.5
+NTT_FIELD_MUL_PER_ELEM = {20: 11.0, 22: 13.0, 24: 14.5, 26: 15.5}
 STAGES = ("msm_total", "msm_digits", "msm_sort", "msm_accum", "msm_reduce")  # over-full buckets are summed inside the accumulate launch
 
 
@@ -174,6 +178,8 @@ def main():
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-sizes", action="store_true", help="skip the other sizes (2^22..2^26 MSM, 2^20..2^26 NTT, host-pointer figures, k = 17 trace)")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the evaluate_h / g_to_lagrange legs (SURVEY.md 8(f).3, (f).4)")
+    ap.add_argument("--config4-log-n", type=int, default=24, help="N > 1: BASELINE.json configs[3], an MSM of 2^this pairs in TOTAL sharded over the N GPUs "
+                    "(strong scaling; 0 = skip)")
     ap.add_argument("--no-inlib", action="store_true", help="N > 1: skip the single-process N-device leg (h2hip_init with N ids)")
     ap.add_argument("--only-step", action="store_true", help="nothing but the timed step (counter passes: one kernel mix per run)")
     ap.add_argument("--only-ntt", action="store_true", help="nothing but the NTT leg (counter passes)")
@@ -183,6 +189,7 @@ def main():
     if args.only_step or args.only_ntt:
         args.no_cpu_baseline = args.no_sizes = args.no_next_rows = args.no_inlib = True
         args.batch = 0
+        args.config4_log_n = 0
         args.no_ntt = args.only_step
     if args.inlib:
         return inlib_child(args)
@@ -307,6 +314,75 @@ def main():
         ms, cnt = h2.profile_get(st)
         stages[st] = ms / cnt if cnt else None
 
+    # ---- N > 1: BASELINE.json configs[3] -- ONE MSM of 2^24 pairs in total, sharded over the N GPUs (strong scaling: 2^24 / N pairs per
+    # rank, fixed-base, 96-byte partials all-gathered over RCCL and folded on every rank), next to the weak-scaling figure above ----
+    config4 = None
+    if world > 1 and args.config4_log_n:
+        n4 = 1 << args.config4_log_n
+        lo4, hi4 = h2dist.shard_range(n4, rank, world)
+        ds4 = h2.gen_scalars_device(0x5EED0001, hi4 - lo4, start=lo4, device=dev)
+        dp4 = h2.gen_points_device(0x5EED0002, hi4 - lo4, start=lo4, device=dev)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        h2.bases_pin_device(dp4)
+        pin4_s = time.perf_counter() - t1
+        info4 = h2.bases_pinned_info(dp4)
+        pend4 = [None, 0]
+
+        def step4():
+            part = h2.msm_device(ds4, dp4)
+            done = h2dist.allgather_finish(pend4[0], h2) if pend4[0] is not None else None
+            pend4[0] = h2dist.allgather_start(part, device=gather_dev, slot=pend4[1])
+            pend4[1] ^= 1
+            return done
+
+        def drain4():
+            out4 = h2dist.allgather_finish(pend4[0], h2)
+            pend4[0] = None
+            return out4
+
+        for _ in range(2):
+            step4()
+        drain4()
+        k4 = 5
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(k4):
+            step4()
+        r4 = drain4()
+        sync_all()
+        el4 = time.perf_counter() - t1
+        aff4 = h2.g1_to_affine(r4)
+        # every rank folded the same gathered partials itself: all N folds must be one group element
+        lim = torch.from_numpy(aff4.view(np.int64).copy())
+        red_dev = dev if args.backend == "nccl" else "cpu"
+        tmax, tmin = lim.to(red_dev).clone(), lim.to(red_dev).clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        te = torch.tensor([el4], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        el4 = float(te.item())
+        h2.bases_unpin_device(dp4)
+        del ds4, dp4
+        torch.cuda.empty_cache()
+        config4 = {"workload": "bn254_g1_msm_2p%d_total_sharded_over_%d_gpus" % (args.config4_log_n, world), "scaling": "strong", "pairs_total": n4,
+                   "pairs_per_rank": n4 // world, "window_bits": info4[1], "windows": info4[2], "pin_s": pin4_s, "table_bytes_per_rank": info4[3],
+                   "steps": k4, "ms_per_msm": el4 / k4 * 1e3, "value": n4 * info4[2] / (el4 / k4), "unit": "G1-adds/s", "pairs_per_s": n4 / (el4 / k4),
+                   "same_group_element_on_every_rank": bool(torch.equal(tmax, tmin)),
+                   "note": "time = max over ranks between two barriers; the gather of step i travels under the MSM of step i + 1, all folds inside"}
+        if rank == 0 and n4 <= (1 << 26):  # and the sharded sum equals the same MSM computed whole on ONE GPU (plain form, no table)
+            whole = None
+            for o in range(0, n4, 1 << 24):
+                m_ = min(1 << 24, n4 - o)
+                ds_ = h2.gen_scalars_device(0x5EED0001, m_, start=o, device=dev)
+                dp_ = h2.gen_points_device(0x5EED0002, m_, start=o, device=dev)
+                part_ = h2.msm_device(ds_, dp_)
+                whole = part_ if whole is None else h2.g1_fold(np.stack([whole, part_]))
+                del ds_, dp_
+            config4["same_group_element_as_one_gpu"] = bool(np.array_equal(h2.g1_to_affine(whole), aff4))
+            torch.cuda.empty_cache()
+        sync_all()
+
     solo = rank == 0 and world == 1
 
     # ---- the other form of the same MSM (plain when the step is fixed-base and vice versa), rank 0, N = 1 ----
@@ -384,14 +460,55 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / (2 * reps)
         gbps = NTT_BYTES_PER_ELEM * (1 << k) / (ms * 1e-3) / 1e9
-        return {"log_n": k, "ms_per_transform": ms, "elems_per_s": (1 << k) / (ms * 1e-3),
-                "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
-                             # PMC bytes of one transform = sum over its passes (committed --pmc runs, 2^22 only)
-                             "traffic": pmc_traffic("ntt_2p22") if k == 22 else None}}
+        pt = {"log_n": k, "ms_per_transform": ms, "elems_per_s": (1 << k) / (ms * 1e-3),
+              "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                           # PMC bytes of one transform = sum over its passes (committed --pmc runs, 2^22 only)
+                           "traffic": pmc_traffic("ntt_2p22") if k == 22 else None}}
+        if k in NTT_FIELD_MUL_PER_ELEM:  # the roofline that binds: Fr multiplications per second against the multiplier's measured peak
+            gmul = NTT_FIELD_MUL_PER_ELEM[k] * (1 << k) / (ms * 1e-3) / 1e9
+            pt["valu_roofline"] = {"bound": "valu-int", "field_mul_per_elem": NTT_FIELD_MUL_PER_ELEM[k], "achieved": gmul, "peak": FIELD_MUL_PEAK_G,
+                                   "unit": "Gmul/s", "frac": gmul / FIELD_MUL_PEAK_G}
+        return pt
+
+    def ntt_cpu_baseline(k):
+        """the oracle's best_fft (arithmetic.rs:171-234 restated, same thread split) on the host cores: forward transform of 2^k elements,
+        median of up to 5 runs within ~10 s; also the parity check of the GPU's forward transform on the same input"""
+        from oracle import oracle
+        d = h2.EvaluationDomain.new(2, k)
+        d_a = h2.gen_scalars_device(0x5EED0003, 1 << k, device=dev)
+        a = h2.to_numpy_u64(d_a).copy()
+        h2.ntt_device(d_a, d.omega, k)
+        torch.cuda.synchronize()
+        got = h2.to_numpy_u64(d_a)
+        hw = os.cpu_count() or 1
+        res = {}
+        want = None
+        for T, budget in ((hw, 10.0), (min(16, hw), 8.0)):
+            if T in res:
+                continue
+            oracle.best_fft(a[:1 << 12], h2.EvaluationDomain.new(2, 12).omega, 12, T)  # warm the thread pool
+            ts = []
+            stop = time.perf_counter() + budget
+            while len(ts) < 5 and time.perf_counter() < stop:
+                t1 = time.perf_counter()
+                want = oracle.best_fft(a, d.omega, k, T)
+                ts.append(time.perf_counter() - t1)
+            res[T] = (sorted(ts)[len(ts) // 2], len(ts))
+        t_hw, runs = res[hw]
+        out = {"value": (1 << k) / t_hw, "unit": "elems/s", "cores": hw, "cpu_model": cpu_model(), "kind": "port",
+               "sample": "full 2^%d-element forward transform, median of %d runs, %.3f s each, T = os.cpu_count() = %d threads; C restatement of "
+                         "best_fft (serial bit-reversal and twiddle scan, then the rayon::join recursion), not the Rust binary" % (k, runs, t_hw, hw),
+               "parity_vs_cpu": bool(np.array_equal(got, want))}
+        sh = min(16, hw)
+        if sh != hw:
+            out["share_16_threads"] = {"cores": sh, "seconds": res[sh][0], "elems_per_s": (1 << k) / res[sh][0]}
+        return out
 
     ntt = None
     if not args.no_ntt and rank == 0:
         ntt = ntt_point(args.ntt_log_n, 10)
+        if solo and not args.no_cpu_baseline:
+            ntt["cpu_baseline"] = ntt_cpu_baseline(args.ntt_log_n)
 
     # ---- the sizes DESIGN.md quotes, measured by this run (rank 0, N = 1) ----
     sizes = None
@@ -481,7 +598,11 @@ def main():
         import trace_bench
         sizes["trace_k17"] = trace_bench.run(h2, cpu=False)
         pl = trace_bench.run(h2, cpu=False, scalars="prover-like")  # SURVEY.md 8(d) config 5's second distribution
-        sizes["trace_k17_prover_like"] = {k_: pl[k_] for k_ in ("scalars", "single_ms", "batched_ms")}
+        sizes["trace_k17_prover_like"] = {k_: pl[k_] for k_ in ("scalars", "single_ms", "batched_ms", "reps_ms")}
+        # the same 37 calls on HOST columns (what the shipped patches produce: 0001 + 0002 one call each, + 0004 / 0005 batched), PCIe included
+        sizes["trace_k17_host"] = trace_bench.run_host(h2)
+        import host_ntt_batch
+        sizes["host_pointer"]["ntt_batch"] = host_ntt_batch.bench(h2, log_ns=(args.ntt_log_n,), counts=(4, 8))
 
     # ---- SURVEY.md 8(f).3 / (f).4 legs (extra keys; rank 0, N = 1 only), outside the MSM timed region ----
     next_rows = None
@@ -628,6 +749,7 @@ def main():
             "sizes": sizes,
             "next_rows": next_rows,
             "in_library_multi_gpu": inlib,
+            "config4": config4,
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)

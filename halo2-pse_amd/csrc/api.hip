@@ -38,6 +38,7 @@ void msm_set_split_records(bool on);
 void msm_set_bucket_order(int local);
 void msm_set_quad_tail(bool on);
 void msm_set_split_buckets(bool on);
+void msm_set_plane_tail(bool on);
 void ecfft_set_quad(bool on);
 void msm_set_fuse_limits(size_t entries, size_t max_n);
 void msm_set_rowcol(uint64_t lanes, uint32_t flavour);
@@ -942,6 +943,7 @@ static void release_ctx(Ctx* c) {
     }
     c->msm_bases.release();
     c->host_ws.release();
+    c->host_planes.release();
     c->stage.release();
     c->stage_off = 0;
     c->misc.release();
@@ -2219,6 +2221,13 @@ int h2hip_debug_set_msm_split_buckets(int on) {
 }
 
 // tuning hook: the reduction tail with one quad of lanes per group operation (1, default) or one lane (0)
+int h2hip_debug_set_msm_plane_tail(int on) {
+    Entry en;
+    if (en.rc) return en.rc;
+    msm_set_plane_tail(on != 0);
+    return 0;
+}
+
 int h2hip_debug_set_msm_quad_tail(int on) {
     msm_set_quad_tail(on != 0);
     return 0;

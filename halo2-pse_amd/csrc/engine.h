@@ -141,6 +141,7 @@ struct Ctx {
     std::recursive_mutex mu;       // serialises entry points: re-entrant callers (rayon workers) are safe
     DevBuf ntt_ws, ntt_io, msm_scalars[3], msm_bases, msm_slot[3], misc, evalh_ws, evalh_slots, ecfft_ws, ntt_ptrs, gather, gen_table;
     HostBuf host_ws;               // pinned host memory for the window sums coming back
+    HostBuf host_planes;           // ... and for the bit-plane sums of a run whose tail the host finishes (msm.hip msm_planes_finish)
     HostBuf pin_flag;              // one word the device-key fingerprint check writes its verdict to
     // a fingerprint check the next MSM run's first kernel carries out (msm_l1_count_kernel's first workgroup: no launch of its own);
     // set by msm_device_keyed around its msm_batch_device call, taken by the first msm_stage_a

@@ -976,6 +976,87 @@ __global__ void __launch_bounds__(64) msm_final_quad_kernel(FinalArgs args, uint
     if (threadIdx.x == 0) set_sums[set] = xyzzu_to_ext(sh[0]);
 }
 
+// ---- the tail of a run with few bucket sets (a lone commit), round 4: bit planes on the GPU, Horner on the host ----
+// After the first row / column pass a set is sum_h (h << s) R_h + sum_l (l + 1) C_l over 2^rb + 2^s points.  Until round 4 a second
+// pass and msm_final_quad_kernel finished it on a handful of waves: every remaining point scaled by its weight (~cb dependent quad
+// doublings at 1.7 us, a few quad additions at 4 us) and two trees -- 0.12 ms of a 2^20-pair MSM, 0.09 of a 2^17-pair one, all latency.
+// The weights are only cb bits wide: with T_j = the plain sum of the points whose weight has bit j set, the set is sum_j 2^j T_j.
+// The T_j are independent trees (this kernel: one workgroup per 128 points of a plane, seven levels of quad additions; the workgroup
+// that arrives last for its plane adds the plane's partials), and the cb doublings + cb additions that remain are a dependent chain
+// of exactly the kind a host core runs eight times faster than a quad of lanes (0.35 / 0.5 us per 4 x 64-bit-limb doubling / addition
+// against 1.7 / 4 us): the plane sums go to pinned host memory and msm_planes_finish runs the Horner there.
+#define MSM_PLANES_MAX 32      // planes per set the host buffer is sized for (cb <= 23 -> at most s + 1 + rb <= 25)
+#define MSM_PLANE_SETS_MAX 4   // runs with more sets keep the GPU tail (the host chain is serial per set)
+struct PlaneJob {
+    const XYZZu* base;    // array of set 0: R (weights i << s) or C (weights i + 1)
+    uint32_t log_len;     // 2^log_len elements per set
+    uint32_t o;           // weight of element i is (i + o), o in {0, 1}; the shift of R is applied by the host
+    uint32_t n_planes;    // log_len for o = 0; log_len + 1 for o = 1 (the weight 2^log_len of the last element)
+    uint32_t wgs;         // workgroups per plane
+    uint32_t first_plane; // index of this job's plane 0 among the set's planes
+    uint32_t first_block; // of set 0; a set takes blocks_per_set blocks
+};
+struct PlaneArgs {
+    PlaneJob job[2];
+    uint32_t blocks_per_set, planes_per_set;
+};
+
+__global__ void __launch_bounds__(256) msm_planes_kernel(PlaneArgs args, XYZZu* __restrict__ partials, uint32_t* __restrict__ done,
+                                                         XYZZ* __restrict__ plane_sums) {
+    __shared__ XYZZu sh[64];
+    __shared__ uint32_t is_last;
+    const uint32_t set = blockIdx.x / args.blocks_per_set, b = blockIdx.x - set * args.blocks_per_set;
+    const PlaneJob& J = args.job[b >= args.job[1].first_block ? 1 : 0];
+    const uint32_t pb = b - J.first_block, plane = pb / J.wgs, part = pb - plane * J.wgs;
+    const XYZZu* X = J.base + ((size_t)set << J.log_len);
+    const uint32_t quad = threadIdx.x >> 2, role = threadIdx.x & 3;
+    // element t of plane j < log_len: the t-th value v in [0, 2^log_len) with bit j set, i.e. a one inserted at bit j of t; index v - o.
+    // Plane log_len (o = 1 only) is the single element whose weight is 2^log_len: the last one.
+    const bool top = plane == J.log_len;
+    const uint32_t count = top ? 1u : 1u << (J.log_len - 1);
+    auto elem = [&](uint32_t t) -> XYZZu {
+        if (t >= count) return xyzzu_identity();
+        const uint32_t v = top ? (1u << J.log_len) : ((t >> plane) << (plane + 1)) | (1u << plane) | (t & ((1u << plane) - 1));
+        return X[v - J.o];
+    };
+    const uint32_t t0 = part * 128 + 2 * quad;
+    const XYZZu x = xyzzu_sum_q(elem(t0), elem(t0 + 1), role);
+    if (role == 0) sh[quad] = x;
+    __syncthreads();
+    for (uint32_t st = 32; st >= 1; st >>= 1) {
+        if (quad < st) {
+            const XYZZu a = xyzzu_sum_q(sh[quad], sh[quad + st], role);
+            if (role == 0) sh[quad] = a;
+        }
+        __syncthreads();
+    }
+    const uint32_t out = set * args.planes_per_set + J.first_plane + plane;
+    if (J.wgs == 1) {
+        if (threadIdx.x == 0) plane_sums[out] = xyzzu_to_ext(sh[0]);
+        return;
+    }
+    if (threadIdx.x == 0) {
+        partials[(size_t)out * 16 + part] = sh[0];
+        __threadfence();
+        is_last = atomicAdd(&done[out], 1u) == J.wgs - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other workgroups' partials, written before their arrivals
+    XYZZu y = xyzzu_identity();
+    if (quad < J.wgs) y = partials[(size_t)out * 16 + quad];
+    if (role == 0 && quad < 16) sh[quad] = y;
+    __syncthreads();
+    for (uint32_t st = 8; st >= 1; st >>= 1) {
+        if (quad < st) {
+            const XYZZu a = xyzzu_sum_q(sh[quad], sh[quad + st], role);
+            if (role == 0) sh[quad] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) plane_sums[out] = xyzzu_to_ext(sh[0]);
+}
+
 // Fixed-base table, one step: out[i] = 2^c * prev[i] (XYZZ; normalised to affine by ec_normalize afterwards)
 __global__ void __launch_bounds__(256) msm_table_step_kernel(const Affine* __restrict__ prev, XYZZ* __restrict__ out, uint32_t n, uint32_t c) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1122,7 +1203,7 @@ struct MsmLayout {
     uint32_t levels, s, rb, s2, s3;
     size_t max_chunks, max_heavy;
     size_t o_zero, o_zero_end, o_bintot, o_hist, o_hcnt, o_fdone, o_cstart, o_tmp, o_vals, o_start, o_counts, o_perm, o_buckets, o_parts, o_RA, o_CA, o_RR,
-        o_RC, o_CR, o_CC, o_sums, o_partials, o_hb, o_hc, o_hs, o_ptrs, o_thist, o_toff, o_chsum, total;
+        o_RC, o_CR, o_CC, o_sums, o_partials, o_ppart, o_hb, o_hc, o_hs, o_ptrs, o_thist, o_toff, o_chsum, total;
 };
 
 // force_c / force_split: the chunks of a streamed MSM (msm_stream_host) all use the window width and the lanes-per-bucket
@@ -1214,6 +1295,7 @@ static int msm_layout(size_t n, MsmLayout* L, uint32_t fuse, const MsmTable* tab
     L->o_CC = carve(((size_t)ns << L->s3) * sizeof(XYZZu));
     L->o_sums = carve((size_t)ns * sizeof(XYZZ));
     L->o_partials = carve((size_t)ns * 16 * sizeof(XYZZu));
+    L->o_ppart = carve(ns <= MSM_PLANE_SETS_MAX ? (size_t)ns * MSM_PLANES_MAX * 16 * sizeof(XYZZu) : 0);  // plane partials of the host-finished tail
     L->o_ptrs = carve((size_t)fuse * sizeof(void*));
     // -- regions sized by the entries of the run
     L->o_thist = carve((size_t)L->n_tiles * L->C1 * 2);
@@ -1374,8 +1456,35 @@ static void rowcol_jobs(RowColArgs* ra, const XYZZu* in, XYZZu* out_rows, XYZZu*
     }
 }
 
-// stage C (latency-bound): bucket reduction to one sum per set, copied to h_sums (host)
-static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_sums, hipStream_t s) {
+static bool g_plane_tail = true;
+void msm_set_plane_tail(bool on) { g_plane_tail = on; }
+// whether a run's tail is finished on the host from bit-plane sums (msm_planes_kernel): few sets, one row / column level at least,
+// at most 16 workgroups (2^11 points) per plane, and the sums not wanted in HBM for the RCCL gather
+static bool msm_plane_tail(const Ctx* c, const MsmLayout& L) {
+    return g_plane_tail && g_quad_tail && L.levels >= 1 && L.n_sets <= MSM_PLANE_SETS_MAX && L.rb <= 11 && L.s <= 11 && L.rb >= 1 && L.s >= 1 &&
+           L.s + 1 + L.rb <= MSM_PLANES_MAX && !c->gather_want;
+}
+static inline uint32_t msm_planes_per_set(const MsmLayout& L) { return L.rb + L.s + 1; }
+
+// host side of the plane tail: set = sum_j 2^j C-plane_j + sum_j 2^(s + j) R-plane_j, as one Horner from the top (planes: [C 0..s | R 0..rb-1])
+static void msm_planes_finish(const MsmLayout& L, const XYZZ* planes, XYZZ* sums) {
+    const uint32_t pps = msm_planes_per_set(L);
+    for (uint32_t set = 0; set < L.n_sets; set++) {
+        const XYZZ* P = planes + (size_t)set * pps;
+        h64::P acc = h64::identity();
+        for (uint32_t m = L.s + L.rb; m-- > 0;) {
+            acc = h64::pdouble(acc);
+            if (m >= L.s) h64::padd(acc, h64::from_xyzz(P[L.s + 1 + (m - L.s)]));
+            if (m <= L.s) h64::padd(acc, h64::from_xyzz(P[m]));
+        }
+        sums[set] = h64::to_xyzz(acc);
+    }
+}
+
+// stage C (latency-bound): bucket reduction to one sum per set, copied to h_sums (host).  h_planes (optional, pinned host memory for
+// n_sets * MSM_PLANES_MAX points): when the run qualifies (msm_plane_tail) the kernels stop at the bit-plane sums and deliver those
+// instead; the caller then completes h_sums with msm_planes_finish once the stream has drained.
+static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_sums, hipStream_t s, XYZZ* h_planes = nullptr) {
     XYZZu* buckets = (XYZZu*)(base + L.o_buckets);
     XYZZu *RA = (XYZZu*)(base + L.o_RA), *CA = (XYZZu*)(base + L.o_CA), *RR = (XYZZu*)(base + L.o_RR), *RC = (XYZZu*)(base + L.o_RC);
     XYZZu *CR = (XYZZu*)(base + L.o_CR), *CC = (XYZZu*)(base + L.o_CC);
@@ -1413,6 +1522,29 @@ static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_sums, hip
         else
             hipLaunchKernelGGL(msm_rowcol_kernel<FqU>, dim3(nblk), dim3(256), 0, s, ra);
         H2_CHECK(hipGetLastError());
+        if (h_planes && msm_plane_tail(c, L)) {
+            PlaneArgs pa;
+            memset(&pa, 0, sizeof(pa));
+            uint32_t blk = 0, pl = 0;
+            for (uint32_t k = 0; k < 2; k++) {  // [0] the column sums (weights l + 1), [1] the row sums (weights h, shifted by s on the host)
+                PlaneJob& J = pa.job[k];
+                J.base = k ? RA : CA;
+                J.log_len = k ? L.rb : L.s;
+                J.o = k ? 0 : 1;
+                J.n_planes = J.log_len + J.o;
+                J.wgs = J.log_len > 7 ? 1u << (J.log_len - 8) : 1;  // 128 points of a plane's 2^(log_len - 1) per workgroup
+                J.first_plane = pl;
+                J.first_block = blk;
+                pl += J.n_planes;
+                blk += J.n_planes * J.wgs;
+            }
+            pa.blocks_per_set = blk;
+            pa.planes_per_set = pl;
+            hipLaunchKernelGGL(msm_planes_kernel, dim3(ns * blk), dim3(256), 0, s, pa, (XYZZu*)(base + L.o_ppart), (uint32_t*)(base + L.o_fdone), h_planes);
+            H2_CHECK(hipGetLastError());
+            c->timer_end(t4, s);
+            return 0;
+        }
         if (L.levels == 1) {
             set_arr(0, RA, L.rb, 0, L.s);
             set_arr(1, CA, L.s, 1, 0);
@@ -1496,6 +1628,11 @@ static int msm_batch_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_h
     rc = c->host_ws.ensure(count * spm * sizeof(XYZZ));
     if (rc) return rc;
     XYZZ* h_ws = (XYZZ*)c->host_ws.p;
+    XYZZ* h_pl = nullptr;  // a lone MSM: the reduction's tail is finished on the host from bit-plane sums
+    if (count == 1 && msm_plane_tail(c, L)) {
+        if ((rc = c->host_planes.ensure((size_t)L.n_sets * MSM_PLANES_MAX * sizeof(XYZZ)))) return rc;
+        h_pl = (XYZZ*)c->host_planes.p;
+    }
     rc = c->ws_acquire(s);
     if (rc) return rc;
     WsGuard guard(c, s);
@@ -1506,7 +1643,7 @@ static int msm_batch_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_h
         if ((rc = scalars_for(0, s, &sc))) return rc;
         if ((rc = msm_stage_a(c, L, base, &sc, tab, s))) return rc;
         if ((rc = msm_stage_b(c, L, base, d_points, s))) return rc;
-        if ((rc = msm_stage_c(c, L, base, h_ws, s))) return rc;
+        if ((rc = msm_stage_c(c, L, base, h_ws, s, h_pl))) return rc;
     } else {
         // Three internal streams.  A full-size accumulate holds every wave slot for ~0.65 ms at a time, so the other
         // stages only partly overlap with it (trace: profiles/): measured gain 17 % at 2^20, 37 % at 2^17.  Reserving
@@ -1537,6 +1674,7 @@ static int msm_batch_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_h
     }
     c->timer_end(t_all, s);
     H2_CHECK(hipStreamSynchronize(s));
+    if (h_pl) msm_planes_finish(L, h_pl, h_ws);
     for (size_t j = 0; j < count; j++) h_out[j] = finish_msm(h_ws + j * spm, L.p);
     return guard.release();
 }
@@ -1564,13 +1702,19 @@ static int msm_fused_chunk(Ctx* c, const Fe* const* d_scalars, bool scalars_on_h
     }
     if ((rc = c->host_ws.ensure((size_t)L.n_sets * sizeof(XYZZ)))) return rc;
     XYZZ* h_ws = (XYZZ*)c->host_ws.p;
+    XYZZ* h_pl = nullptr;
+    if (msm_plane_tail(c, L)) {
+        if ((rc = c->host_planes.ensure((size_t)L.n_sets * MSM_PLANES_MAX * sizeof(XYZZ)))) return rc;
+        h_pl = (XYZZ*)c->host_planes.p;
+    }
     char* base = (char*)c->msm_slot[0].p;
     int t_all = c->timer_begin("msm_total", s);
     if ((rc = msm_stage_a(c, L, base, list.data(), tab, s))) return rc;
     if ((rc = msm_stage_b(c, L, base, d_points, s))) return rc;
-    if ((rc = msm_stage_c(c, L, base, h_ws, s))) return rc;
+    if ((rc = msm_stage_c(c, L, base, h_ws, s, h_pl))) return rc;
     c->timer_end(t_all, s);
     H2_CHECK(hipStreamSynchronize(s));
+    if (h_pl) msm_planes_finish(L, h_pl, h_ws);
     const uint32_t spm = sets_per_msm(L.p);
     for (size_t j = 0; j < count; j++) h_out[j] = finish_msm(h_ws + j * spm, L.p);
     return guard.release();
@@ -1676,6 +1820,11 @@ static int msm_stream_host(Ctx* c, const Fe* h_scalars, const Affine* h_bases, c
     const uint32_t spm = sets_per_msm(Lt.p);
     if ((rc = c->host_ws.ensure(spm * sizeof(XYZZ)))) return rc;
     XYZZ* h_ws = (XYZZ*)c->host_ws.p;
+    XYZZ* h_pl = nullptr;
+    if (msm_plane_tail(c, Lk[K - 1])) {
+        if ((rc = c->host_planes.ensure((size_t)Lk[K - 1].n_sets * MSM_PLANES_MAX * sizeof(XYZZ)))) return rc;
+        h_pl = (XYZZ*)c->host_planes.p;
+    }
     if ((rc = c->ensure_aux(K + 2))) return rc;
     if ((rc = c->ws_acquire(s))) return rc;
     WsGuard guard(c, s);
@@ -1711,9 +1860,10 @@ static int msm_stream_host(Ctx* c, const Fe* h_scalars, const Affine* h_bases, c
         if ((rc = msm_stage_b(c, Lk[k], base, points0 + o, s, base, k > 0, k + 1 == K))) return rc;
         o += sz[k];
     }
-    if ((rc = msm_stage_c(c, Lk[K - 1], base, h_ws, s))) return rc;
+    if ((rc = msm_stage_c(c, Lk[K - 1], base, h_ws, s, h_pl))) return rc;
     c->timer_end(t_all, s);
     H2_CHECK(hipStreamSynchronize(s));
+    if (h_pl) msm_planes_finish(Lk[K - 1], h_pl, h_ws);
     h_out[0] = finish_msm(h_ws, Lt.p);
     return guard.release();
 }

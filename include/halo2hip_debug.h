@@ -34,6 +34,8 @@ int h2hip_debug_set_msm_rowcol(uint64_t lanes, int use_asm);
 /* accumulation of runs with fewer than 2^18 buckets: up to 8 lanes per bucket (1, default) or one (0) */
 int h2hip_debug_set_msm_split_buckets(int on);
 /* reduction tail: one quad of lanes per group operation (1, default) or one lane each (0) */
+/* runs with at most 4 bucket sets: finish the reduction on the host from bit-plane sums (1, default) or keep the GPU tail (0) */
+int h2hip_debug_set_msm_plane_tail(int on);
 int h2hip_debug_set_msm_quad_tail(int on);
 /* 1: accumulate order = buckets by size inside each sort bin only; 0 (default): global size order */
 int h2hip_debug_set_msm_bucket_order(int local);

@@ -30,7 +30,7 @@ def prover_like(h2, col, seed):
     return col
 
 
-def run(h2, cpu=True, fixed_base=True, scalars="dense"):
+def run(h2, cpu=True, fixed_base=True, scalars="dense", idle_s=0.0, prewarm_ms=100.0, detail=False):
     """returns the result dict; cpu=True also times the oracle on the host cores (imports oracle/: bench/tools only)"""
     import torch
     k = 17
@@ -53,18 +53,49 @@ def run(h2, cpu=True, fixed_base=True, scalars="dense"):
 
     def timed(f, reps=5, name=None):
         """median of `reps` repetitions, each between its own pair of events (round 3 took the mean of three between ONE pair: a single
-        stall owned the figure and nothing showed it was one); the list rides along in the result"""
+        stall owned the figure and nothing showed it was one); the list rides along in the result.  A named leg first runs ~prewarm_ms
+        of untimed repetitions: a chip that has idled (the legs of bench.py ahead of this one are host-bound) runs its first tens of
+        milliseconds at idle clocks -- `--idle S` reproduces that on purpose."""
         f()
         torch.cuda.synchronize()
-        ts = []
-        for _ in range(reps):
-            ev[0].record()
-            f()
-            ev[1].record()
+        if name and idle_s:
+            time.sleep(idle_s)
+        if name and prewarm_ms:
+            t_end = time.perf_counter() + prewarm_ms * 1e-3
+            while time.perf_counter() < t_end:
+                f()
             torch.cuda.synchronize()
-            ts.append(ev[0].elapsed_time(ev[1]))
+        ts, gen2 = [], []
+        # The blocking calls leave the GPU idle whenever the interpreter pauses, so a full (generation-2) garbage collection of a
+        # process that has torch, numpy and half a dozen bench modules loaded -- tens of milliseconds, once in a long while -- lands
+        # inside whichever repetition happens to trigger it.  Round 3's driver line carried one (36 ms "per repetition" = 3 x 7.6 + 85).
+        # The collector is therefore run once up front and kept off during the repetitions; the count of full collections per
+        # repetition rides along as evidence (0 with the collector off; `H2_TRACE_GC=1` leaves it on to show the effect).
+        import gc
+        keep_gc = os.environ.get("H2_TRACE_GC") == "1"
+        if not keep_gc:
+            t_gc = time.perf_counter()
+            gc.collect()
+            if name:  # how long ONE full pass takes in this process: the size of the stall a repetition would have carried
+                rep_log.setdefault("full_gc_pass_ms", []).append(round((time.perf_counter() - t_gc) * 1e3, 2))
+        was_enabled = gc.isenabled()
+        if not keep_gc:
+            gc.disable()
+        try:
+            for _ in range(reps):
+                g2 = gc.get_stats()[2]["collections"]
+                ev[0].record()
+                f()
+                ev[1].record()
+                torch.cuda.synchronize()
+                ts.append(ev[0].elapsed_time(ev[1]))
+                gen2.append(gc.get_stats()[2]["collections"] - g2)
+        finally:
+            if was_enabled:
+                gc.enable()
         if name:
             rep_log[name] = [round(t, 4) for t in ts]
+            rep_log[name + "_full_gc_passes"] = gen2
         return sorted(ts)[len(ts) // 2]
 
     def fill_ext():
@@ -99,7 +130,38 @@ def run(h2, cpu=True, fixed_base=True, scalars="dense"):
 
     out = {"k": k, "extended_k": ek, "fixed_base": fixed_base, "scalars": scalars, "single_ms": timed(single, name="single"),
            "batched_ms": timed(batched, name="batched"), "fill_ext_ms": timed(fill_ext) + timed(restore), "reps_ms": rep_log, "stat": "median of 5",
-           "calls": "16 MSMs of 2^17 (10 commit_lagrange + 6 commit), 10 iNTTs, 10 coset NTTs 2^17 -> 2^19, one inverse coset NTT of 2^19"}
+           "calls": "16 MSMs of 2^17 (10 commit_lagrange + 6 commit), 10 iNTTs, 10 coset NTTs 2^17 -> 2^19, one inverse coset NTT of 2^19",
+           "prewarm_ms": prewarm_ms, "idle_s": idle_s}
+    if detail:  # per-call GPU times of two consecutive repetitions of `single` after an idle gap: is a slow repetition one stall or slow throughout?
+        calls = []
+
+        def single_logged():
+            evs = [torch.cuda.Event(enable_timing=True)]
+            evs[0].record()
+
+            def mark():
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                evs.append(e)
+            restore(); mark()
+            for c in lag:
+                h2.msm_device(c, gl); mark()
+            for c in lag:
+                h2.ifft_device(c, d.omega_inv, k, d.ifft_divisor); mark()
+            for c in lag[:6]:
+                h2.msm_device(c, g); mark()
+            fill_ext(); mark()
+            for e_ in ext:
+                h2.coeff_to_extended_device(e_, k, ek, d.extended_omega, d.g_coset, d.g_coset_inv); mark()
+            h2.extended_to_coeff_device(ext[0], ek, d.extended_omega_inv, d.extended_ifft_divisor, d.g_coset, d.g_coset_inv); mark()
+            torch.cuda.synchronize()
+            calls.append([round(a.elapsed_time(b), 4) for a, b in zip(evs, evs[1:])])
+        time.sleep(max(idle_s, 2.0))
+        single_logged()
+        single_logged()
+        single_logged()
+        out["detail_after_idle_ms"] = {"order": "restore, 10 msm(gl), 10 ifft, 6 msm(g), fill_ext, 10 coset, 1 ext_to_coeff", "reps": calls,
+                                       "totals": [round(sum(c_), 3) for c_ in calls]}
     if fixed_base:
         h2.bases_unpin_device(g)
         h2.bases_unpin_device(gl)
@@ -222,8 +284,10 @@ def main():
     if "--host" in sys.argv:
         print(json.dumps(run_host(h2, scalars="prover-like" if "--prover-like" in sys.argv else "dense")))
         return
+    idle = float(sys.argv[sys.argv.index("--idle") + 1]) if "--idle" in sys.argv else 0.0
     print(json.dumps(run(h2, cpu="--no-cpu" not in sys.argv, fixed_base="--plain" not in sys.argv,
-                         scalars="prover-like" if "--prover-like" in sys.argv else "dense")))
+                         scalars="prover-like" if "--prover-like" in sys.argv else "dense", idle_s=idle,
+                         prewarm_ms=0.0 if "--no-prewarm" in sys.argv else 100.0, detail="--detail" in sys.argv)))
 
 
 if __name__ == "__main__":
