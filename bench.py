@@ -615,7 +615,10 @@ def main():
         next_rows = {
             "evaluate_h": {"workload": "2^20 extended rows (k = 18), %d gate polynomials, %d advice + %d fixed columns, %d permutation columns, "
                                        "%d lookups; device-resident" % (eh["gates"], eh["advice"], eh["fixed"], eh["perm_columns"], eh["lookups"]),
-                           "ms_per_call": eh["k18"]["gpu_ms"], "rows_per_s": eh["k18"]["rows_per_s"],
+                           "ms_per_call": eh["k18"]["gpu_ms"], "rows_per_s": eh["k18"]["rows_per_s"], "gates_kernel": eh["k18"].get("gates_kernel"),
+                           "stage_ms": eh["k18"].get("stage_ms"), "gates_valu_roofline": eh["k18"].get("gates_valu_roofline"),
+                           "with_the_interpreter": eh["k18"].get("interpreter"), "first_call_with_inline_compile_s": eh["k18"].get("first_call_with_inline_compile_s"),
+                           "parity_vs_cpu_k12_generated": eh["check_k12"].get("match_generated"),
                            "parity_vs_cpu_k12": eh["check_k12"]["match"], "cpu_port_s_k12": eh["check_k12"]["oracle_s"],
                            "gpu_ms_k12": eh["check_k12"]["gpu_ms"]},
             "g_to_lagrange": {"k16_ms": gl["k16"]["gpu_ms"], "k16_scalar_muls_per_s": gl["k16"]["scalar_muls_per_s"],

@@ -301,6 +301,7 @@ static void read_config() {
     if (env_u64("HALO2_HIP_ROCTX", &v)) c.roctx = v != 0;
     if (env_u64("HALO2_HIP_LAZY_PIN", &v)) c.lazy_pin_after = (uint32_t)v;
     if (env_u64("HALO2_HIP_NTT_TWIDDLE_MB", &v)) ntt_set_full_twiddle_budget(v << 20);
+    if (env_u64("HALO2_HIP_EVALH_CODEGEN", &v)) evalh_debug_set_codegen((int)v, 0);
     if (env_u64("HALO2_HIP_MSM_WINDOW", &v) && v >= 2 && v <= 24) msm_set_window((uint32_t)v);
     {  // HALO2_HIP_STREAM=0: host-slice MSMs upload whole arrays ahead of the run (no copier thread); HALO2_HIP_STREAM_MIN_N: threshold
         uint64_t on = 1, min_n = 0;
@@ -929,6 +930,7 @@ static void release_ctx(Ctx* c) {
     c->timers_collect();
     c->timers.clear();
     ntt_twiddles_free(c);
+    evalh_modules_free(c);
     for (auto& kv : c->pinned) {
         (void)hipFree(kv.second.d);
         if (kv.second.d_sample) (void)hipFree(kv.second.d_sample);
@@ -1100,6 +1102,7 @@ void h2hip_shutdown(void) {
     }
     g_devs.clear();
     lazy_reset();
+    evalh_rtc_shutdown();
 }
 
 const char* h2hip_last_error(void) { return g_err; }
@@ -2264,6 +2267,25 @@ int h2hip_debug_set_evalh_lookup_group_bytes(uint64_t v) {
 }
 
 // test / tuning hook, needs no GPU: compile a graph as evaluate_h would and report the program's size
+int h2hip_debug_evalh_program_muls(const h2hip_graph* g, uint32_t* n_mul) { return evalh_debug_program_muls(g, n_mul) ? H2HIP_EINVAL : 0; }
+
+int h2hip_debug_set_evalh_codegen(int mode, uint32_t max_ops) {
+    Entry en;
+    if (en.rc) return en.rc;
+    evalh_debug_set_codegen(mode, max_ops);
+    return 0;
+}
+
+int h2hip_debug_evalh_codegen_source(const h2hip_graph* g, char* buf, size_t cap, size_t* len, int compile, double* seconds, size_t* code_bytes) {
+    return evalh_debug_codegen_source(g, buf, cap, len, compile, seconds, code_bytes);
+}
+
+int h2hip_debug_evalh_codegen_stats(uint64_t out[5]) {
+    if (!out) return H2HIP_EINVAL;
+    evalh_debug_codegen_stats(out);
+    return 0;
+}
+
 int h2hip_debug_evalh_compile_stats(const h2hip_graph* g, uint32_t* n_ops, uint32_t* n_slots) {
     return evalh_debug_compile_stats(g, n_ops, n_slots);
 }

@@ -181,6 +181,9 @@ struct Ctx {
     uint32_t aux_reserved = 0xffffffffu;  // CU reservation the aux streams were created with
     std::vector<hipEvent_t> aux_events;
     int ensure_aux(size_t n_events);
+    // evalh.hip: the per-circuit gates kernels loaded on this device, by source hash -> (hipModule_t, hipFunction_t); a pair of nulls
+    // marks a code object that would not load here
+    std::map<uint64_t, std::pair<void*, void*>> evalh_mods;
     Copier* copier[2] = {nullptr, nullptr};  // [0] uploads, [1] downloads; created on first use, joined by copier_stop (release_ctx)
     // multi-device engine, HALO2_HIP_GATHER=rccl: stage C also leaves the run's set sums in `gather` (device memory), from where
     // ncclAllGather takes them; gather_off counts the bytes left there by this call (SIZE_MAX / 2 and up: not one run, unusable)
@@ -248,6 +251,12 @@ int kzg_setup_device(Ctx* c, uint32_t k, const Fe& s, Affine* d_g, Affine* d_gl,
 void evalh_debug_set_max_local_slots(uint32_t v);
 void evalh_debug_set_lookup_group_bytes(uint64_t v);
 int evalh_debug_compile_stats(const h2hip_graph* g, uint32_t* n_ops, uint32_t* n_slots);
+int evalh_debug_program_muls(const h2hip_graph* g, uint32_t* n_mul);
+void evalh_debug_set_codegen(int mode, uint32_t max_ops);  // 0 off, 1 background compile (default), 2 compile inline; max_ops 0 = default
+void evalh_debug_codegen_stats(uint64_t out[5]);            // compiled, failed, generated-kernel launches, interpreter launches, disk-cache hits
+int evalh_debug_codegen_source(const h2hip_graph* g, char* buf, size_t cap, size_t* len, int compile, double* seconds, size_t* code_bytes);
+void evalh_modules_free(Ctx* c);                            // unload this device's generated kernels (release_ctx)
+void evalh_rtc_shutdown();                                  // join the compile threads (h2hip_shutdown)
 int evaluate_h_validate(const h2hip_evalh_desc* d, const void* values);
 int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool dev, hipStream_t s);
 

@@ -10,13 +10,26 @@
 // device with the engine's own coeff_to_extended (ntt.hip), as evaluate_h does at :306-323 and :447-457.
 // Arithmetic is the saturated field.cuh (always canonical): this path is bandwidth- and latency-mixed, not the
 // VALU-bound inner loop of the MSM, and canonical values make bit-exactness with the reference immediate.
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <stdarg.h>
+
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/halo2hip.h"
 #include "engine.h"
+#include "evalh_dev.cuh"
 
 namespace h2 {
 
@@ -44,8 +57,6 @@ enum { OP_ADD = 0, OP_SUB, OP_MUL, OP_SQR, OP_DBL, OP_NEG, OP_MOV, OP_FMA /* dst
 #define EVALH_MAG_RESULT 15.0   // fu_mul_canon needs |value| < 16 r
 #define EVALH_MAG_COLUMN 32.0   // fu_from_ext of a canonical element
 
-typedef FrUA UF;
-
 struct DevOp {
     uint32_t op, dst;
     h2hip_value_source x, y;  // kind INTERMEDIATE: a = slot
@@ -59,22 +70,6 @@ struct ProgDev {
     h2hip_value_source result;
 };
 
-struct ColsDev {
-    const Fe* const* fixed;
-    const Fe* const* advice;
-    const Fe* const* instance;
-    const Fu* challenges;  // I-form, canonical
-    Fu beta, gamma, theta, y;
-    uint32_t log_size;
-    int32_t rot_scale;
-};
-
-// Wave-uniform reads of data that no kernel writes (the program, its constants and rotations, the column pointer
-// tables): read through the constant address space so that they are scalar loads.  Through a generic pointer the
-// compiler must assume the kernel's own stores may alias them and issues one vector load per lane instead (measured:
-// 13 scalar against 1 900 vector memory instructions per wave in the gates kernel).
-#define H2_CONST_AS __attribute__((address_space(4)))
-typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ DevOp ld_op(const DevOp* ops, uint32_t q) {
     const H2_CONST_AS u32x8* p = (const H2_CONST_AS u32x8*)(uintptr_t)ops;
     const u32x8 w = p[q];
@@ -89,24 +84,6 @@ __device__ __forceinline__ DevOp ld_op(const DevOp* ops, uint32_t q) {
     o.y.b = w[7];
     return o;
 }
-__device__ __forceinline__ Fu ld_const_fu(const Fu* tab, uint32_t i) {
-    const H2_CONST_AS int32_t* p = (const H2_CONST_AS int32_t*)(uintptr_t)tab;
-    Fu o;
-#pragma unroll
-    for (int k = 0; k < 9; k++) o.l[k] = p[9 * (size_t)i + k];
-    return o;
-}
-__device__ __forceinline__ int32_t ld_const_i32(const int32_t* tab, uint32_t i) { return ((const H2_CONST_AS int32_t*)(uintptr_t)tab)[i]; }
-__device__ __forceinline__ const Fe* ld_const_col(const Fe* const* tab, uint32_t i) {
-    return (const Fe*)(uintptr_t)((const H2_CONST_AS uint64_t*)(uintptr_t)tab)[i];
-}
-
-__device__ __forceinline__ Fu ld_i(const Fe& x) { return fu_from_ext(x); }                    // E canonical -> I, < 32 r
-__device__ __forceinline__ Fu addn(const Fu& a, const Fu& b) { return fu_norm(fu_add(a, b)); }
-__device__ __forceinline__ Fu subn(const Fu& a, const Fu& b) { return fu_norm(fu_sub(a, b)); }
-__device__ __forceinline__ Fu mul_i(const Fu& a, const Fu& b) { return fu_mul<UF>(a, b); }
-__device__ __forceinline__ Fe out_e(const Fu& a) { return fu_mul_canon<UF>(a, fu_one_e<UF>()); }  // |a| < 16 r -> canonical E
-
 // slot storage: MAXI > 0 -> per-lane scratch; MAXI == 0 -> a global workspace laid out [slot][lane] (coalesced per slot)
 extern __shared__ int32_t evalh_lds[];
 #define EVALH_LDS_HOT 4  // slots of a scratch-tier program that live in LDS (measured, 100 / 400 gates at 2^20 rows: 2 -> 13.1 / 38.7 ms,
@@ -158,11 +135,6 @@ struct Slots<0> {
     __device__ __forceinline__ Fu get(uint32_t i) const { return base[i * stride]; }
     __device__ __forceinline__ void set(uint32_t i, const Fu& x) { base[i * stride] = x; }
 };
-
-// get_rotation_idx (evaluation.rs:32-34): size is a power of two, so rem_euclid is a mask
-__device__ __forceinline__ uint32_t rot_idx(uint32_t idx, int32_t rot, int32_t rot_scale, uint32_t log_size) {
-    return (uint32_t)((int32_t)idx + rot * rot_scale) & ((1u << log_size) - 1);
-}
 
 // ValueSource::get (evaluation.rs:68-103)
 template <class S>
@@ -550,6 +522,426 @@ static Program compile_graph(const h2hip_graph& g) {
     return P;
 }
 
+// ---- the gates kernel generated per circuit (round 4) -------------------------------------------------------------------------------
+// The interpreter above pays, per operation and wave, an eight-dword scalar load of the op, two wave-uniform switches and nine LDS
+// dwords in and out of a slot: 38 k VALU instructions per wave for a 24-gate program whose arithmetic is ~31 k, at 64-75 % of the
+// issue rate because every operation waits for its LDS traffic.  A circuit's program never changes, so it is also emitted as
+// straight-line HIP source -- one statement per operation, slots as local variables (registers, allocated by the compiler),
+// constants as literals, rotations folded into index variables -- and compiled for gfx950 by hiprtc (dlopen'ed; in-memory headers =
+// the library's own field.cuh / fieldu.cuh / evalh_dev.cuh, embedded as text).  The arithmetic per row is the interpreter's,
+// operation for operation, so the values are the same limb for limb.  Compilation takes a second or more: it runs on a background
+// thread the first time a program is seen (HALO2_HIP_EVALH_CODEGEN=1, default) while the interpreter serves the calls in between;
+// code objects are cached per process by source hash and, with HALO2_HIP_CACHE_DIR set, on disk.  =2 compiles inline (tests), =0 off.
+static int g_evalh_codegen = 1;
+// Programs beyond these stay with the interpreter.  hiprtc takes ~20 ms per operation (0.6 s for a dozen, 4 s for 190, 7 s for 315:
+// every field multiplication is ~200 inlined instructions), and a program with many values alive at once spends minutes in the
+// register allocator (100 live slots = 900 VGPRs of state: 205 s) for a kernel that would spill anyway.
+static uint32_t g_evalh_codegen_max_ops = 1200;
+#define EVALH_CODEGEN_MAX_SLOTS 48
+static bool g_evalh_gen_fuse = true;  // two products meeting in a sum share one reduction (gen_source); mode + 16 turns it off (A/B, tests)
+void evalh_debug_set_codegen(int mode, uint32_t max_ops) {
+    g_evalh_codegen = mode & 15;
+    g_evalh_gen_fuse = !(mode & 16);
+    g_evalh_codegen_max_ops = max_ops ? max_ops : 1200;
+}
+struct RtcStats {
+    std::atomic<uint64_t> compiled{0}, failed{0}, launches{0}, interpreted{0}, disk_hits{0};
+};
+static RtcStats g_rtc_stats;
+void evalh_debug_codegen_stats(uint64_t out[5]) {
+    out[0] = g_rtc_stats.compiled;
+    out[1] = g_rtc_stats.failed;
+    out[2] = g_rtc_stats.launches;
+    out[3] = g_rtc_stats.interpreted;
+    out[4] = g_rtc_stats.disk_hits;
+}
+
+#include "rtc_headers.inc"
+
+struct Hiprtc {
+    void* lib = nullptr;
+    hiprtcResult (*Create)(hiprtcProgram*, const char*, const char*, int, const char* const*, const char* const*) = nullptr;
+    hiprtcResult (*Compile)(hiprtcProgram, int, const char* const*) = nullptr;
+    hiprtcResult (*GetCodeSize)(hiprtcProgram, size_t*) = nullptr;
+    hiprtcResult (*GetCode)(hiprtcProgram, char*) = nullptr;
+    hiprtcResult (*GetLogSize)(hiprtcProgram, size_t*) = nullptr;
+    hiprtcResult (*GetLog)(hiprtcProgram, char*) = nullptr;
+    hiprtcResult (*Destroy)(hiprtcProgram*) = nullptr;
+};
+static Hiprtc g_hiprtc;
+static std::mutex g_rtc_mu;  // g_hiprtc, g_rtc
+
+static bool hiprtc_load() {  // under g_rtc_mu
+    Hiprtc& r = g_hiprtc;
+    if (r.lib) return true;
+    void* h = dlopen("libhiprtc.so.7", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("libhiprtc.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/libhiprtc.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return false;
+    r.Create = (decltype(r.Create))dlsym(h, "hiprtcCreateProgram");
+    r.Compile = (decltype(r.Compile))dlsym(h, "hiprtcCompileProgram");
+    r.GetCodeSize = (decltype(r.GetCodeSize))dlsym(h, "hiprtcGetCodeSize");
+    r.GetCode = (decltype(r.GetCode))dlsym(h, "hiprtcGetCode");
+    r.GetLogSize = (decltype(r.GetLogSize))dlsym(h, "hiprtcGetProgramLogSize");
+    r.GetLog = (decltype(r.GetLog))dlsym(h, "hiprtcGetProgramLog");
+    r.Destroy = (decltype(r.Destroy))dlsym(h, "hiprtcDestroyProgram");
+    if (!r.Create || !r.Compile || !r.GetCodeSize || !r.GetCode || !r.GetLogSize || !r.GetLog || !r.Destroy) return false;
+    r.lib = h;
+    return true;
+}
+
+// the program as HIP source.  Operands: constants are literals (I-form limbs), slots are locals, a column operand is a load at the
+// row index of its rotation (one index variable per distinct rotation), challenges and beta / gamma / theta / y come with the launch.
+static bool g_evalh_gen_barriers = true;
+static std::string gen_source(const h2hip_graph& g, const Program& P) {
+    const bool sched_barriers = g_evalh_gen_barriers;
+    std::string src;
+    src.reserve(64 * P.ops.size() + 4096);
+    char buf[512];
+    auto add = [&](const char* fmt, ...) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        src += buf;
+    };
+    std::vector<uint8_t> use_const(g.n_constants, 0), use_rot(g.n_rotations, 0);
+    std::vector<std::vector<uint8_t>> use_col(3);
+    auto note = [&](const h2hip_value_source& v) {
+        if (v.kind == H2HIP_VS_CONSTANT) use_const[v.a] = 1;
+        if (v.kind == H2HIP_VS_FIXED || v.kind == H2HIP_VS_ADVICE || v.kind == H2HIP_VS_INSTANCE) {
+            std::vector<uint8_t>& u = use_col[v.kind - H2HIP_VS_FIXED];
+            if (u.size() <= v.a) u.resize((size_t)v.a + 1, 0);
+            u[v.a] = 1;
+            use_rot[v.b] = 1;
+        }
+    };
+    for (const DevOp& o : P.ops) {
+        note(o.x);
+        note(o.y);
+    }
+    note(P.result);
+    static const char* const tab_name[3] = {"fixed", "advice", "instance"};
+    static const char col_name[3] = {'F', 'A', 'N'};
+    auto operand = [&](const h2hip_value_source& v) -> std::string {
+        char t[96];
+        switch (v.kind) {
+            case H2HIP_VS_CONSTANT: snprintf(t, sizeof(t), "K%u", v.a); break;
+            case H2HIP_VS_INTERMEDIATE: snprintf(t, sizeof(t), "s%u", v.a); break;
+            case H2HIP_VS_FIXED: case H2HIP_VS_ADVICE: case H2HIP_VS_INSTANCE:
+                snprintf(t, sizeof(t), "ld_i(%c%u[r%u])", col_name[v.kind - H2HIP_VS_FIXED], v.a, v.b);
+                break;
+            case H2HIP_VS_CHALLENGE: snprintf(t, sizeof(t), "ld_const_fu(c.challenges, %u)", v.a); break;
+            case H2HIP_VS_BETA: return "c.beta";
+            case H2HIP_VS_GAMMA: return "c.gamma";
+            case H2HIP_VS_THETA: return "c.theta";
+            case H2HIP_VS_Y: return "c.y";
+            case H2HIP_VS_PREVIOUS: return "prev";
+            default: return "fu_zero()";
+        }
+        return t;
+    };
+    src += "#include \"evalh_dev.cuh\"\nusing namespace h2;\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) evalh_gates_gen(ColsDev c, Fe* __restrict__ values) {\n"
+           "    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;\n"
+           "    if (idx >= (1u << c.log_size)) return;\n"
+           "    const Fe prev_e = values[idx];\n"
+           "    const Fu prev = ld_i(prev_e);\n"
+           "    (void)prev;\n";
+    for (uint32_t i = 0; i < g.n_constants; i++)
+        if (use_const[i]) {
+            const Fu k = to_i(load_fe(g.constants + 4 * (size_t)i));
+            add("    const Fu K%u = {{%d, %d, %d, %d, %d, %d, %d, %d, %d}};\n", i, k.l[0], k.l[1], k.l[2], k.l[3], k.l[4], k.l[5], k.l[6], k.l[7], k.l[8]);
+        }
+    for (int t = 0; t < 3; t++)
+        for (uint32_t i = 0; i < use_col[t].size(); i++)
+            if (use_col[t][i]) add("    const Fe* __restrict__ %c%u = ld_const_col(c.%s, %u);\n", col_name[t], i, tab_name[t], i);
+    for (uint32_t i = 0; i < g.n_rotations; i++)
+        if (use_rot[i]) add("    const uint32_t r%u = rot_idx(idx, %d, c.rot_scale, c.log_size);\n", i, g.rotations[i]);
+    if (P.n_slots) {
+        src += "    Fu s0";
+        for (uint32_t i = 1; i < P.n_slots; i++) add(", s%u", i);
+        src += ";\n";
+    }
+    // Two products that meet in a sum or difference share ONE Montgomery reduction (fu_mul_sub: (ab - cd) / 2^261, the columns of both
+    // products in one accumulator; a sum passes -c): a product whose only reader is the next ADD / SUB / Horner step on its slot is not
+    // emitted where the program has it but inside that reader.  Per gate of the usual shape -- selector * (product - product + ...)
+    // folded with y -- that is two of six reductions.  The value is the same field element (the reduced representative may differ by a
+    // multiple of r before the closing exact reduction, which the interpreter's magnitude bounds cover: the fused form's bound,
+    // (|a||b| + |c||d|) / 169 + 1, is below the sum of the two separate ones).
+    const size_t n_ops = P.ops.size();
+    std::vector<int> fused_into(n_ops, -1);  // product i is emitted inside op fused_into[i]
+    if (g_evalh_gen_fuse) {
+        auto is_slot = [](const h2hip_value_source& v) { return v.kind == H2HIP_VS_INTERMEDIATE; };
+        for (size_t i = 0; i < n_ops; i++) {
+            const DevOp& m = P.ops[i];
+            if (m.op != OP_MUL) continue;  // (a product carrying a reduction request stays where it is)
+            const uint32_t X = m.dst;
+            int reader = -1;
+            bool ok = true;
+            for (size_t j = i + 1; j < n_ops && ok; j++) {
+                const DevOp& o = P.ops[j];
+                const uint32_t k = o.op & 0xff;
+                const bool rx = is_slot(o.x) && o.x.a == X, ry = is_slot(o.y) && o.y.a == X, rd = k == OP_FMA && o.dst == X;
+                if (reader < 0) {
+                    if (rx || ry || rd) {
+                        // the one reader: an ADD / SUB taking it as either operand (not both), or a Horner step taking it as the addend
+                        if ((k == OP_ADD || k == OP_SUB) && rx != ry && !rd) reader = (int)j;
+                        else if (k == OP_FMA && rx && !ry && !rd) reader = (int)j;
+                        else ok = false;
+                        if (ok && o.dst == X) break;  // the reader overwrites the slot: nothing later sees the product
+                        continue;
+                    }
+                    if (o.dst == X) ok = false;  // overwritten unread: dead code the compiler kept (cannot happen), leave it alone
+                    // the product's own operands must still hold their values when the reader runs
+                    if ((is_slot(m.x) && o.dst == m.x.a) || (is_slot(m.y) && o.dst == m.y.a)) ok = false;
+                } else {
+                    if (rx || ry || rd) ok = false;   // a second reader
+                    else if (o.dst == X) break;       // overwritten: the product was dead after its one reader
+                }
+            }
+            if (ok && reader >= 0 && !(is_slot(P.result) && P.result.a == X && P.ops[reader].dst != X)) fused_into[i] = reader;
+        }
+        // an ADD / SUB fuses only when BOTH operands are such products; a Horner step when its addend is
+        std::vector<int> cnt(n_ops, 0);
+        for (size_t i = 0; i < n_ops; i++)
+            if (fused_into[i] >= 0) cnt[fused_into[i]]++;
+        for (size_t i = 0; i < n_ops; i++)
+            if (fused_into[i] >= 0) {
+                const uint32_t k = P.ops[fused_into[i]].op & 0xff;
+                if ((k == OP_ADD || k == OP_SUB) && cnt[fused_into[i]] != 2) fused_into[i] = -1;
+            }
+    }
+    auto product_of = [&](size_t j, const h2hip_value_source& v) -> const DevOp* {  // the product fused into op j that v names
+        for (size_t i = 0; i < j; i++)
+            if (fused_into[i] == (int)j && v.kind == H2HIP_VS_INTERMEDIATE && P.ops[i].dst == v.a) return &P.ops[i];
+        return nullptr;
+    };
+    for (size_t q = 0; q < n_ops; q++) {
+        const DevOp& o = P.ops[q];
+        if (fused_into[q] >= 0) continue;  // emitted inside its reader
+        const std::string x = operand(o.x), y = operand(o.y);
+        const uint32_t dst = o.dst;
+        const DevOp *px = product_of(q, o.x), *py = product_of(q, o.y);
+        const uint32_t kind = o.op & 0xff;
+        if ((kind == OP_ADD || kind == OP_SUB) && px && py) {
+            add("    s%u = fu_mul_sub<UF>(%s, %s, ", dst, operand(px->x).c_str(), operand(px->y).c_str());
+            add(kind == OP_SUB ? "%s, %s);\n" : "fu_neg(%s), %s);\n", operand(py->x).c_str(), operand(py->y).c_str());
+        } else if (kind == OP_FMA && px) {
+            add("    s%u = fu_mul_sub<UF>(s%u, %s, fu_neg(%s), %s);\n", dst, dst, y.c_str(), operand(px->x).c_str(), operand(px->y).c_str());
+        } else
+        switch (kind) {
+            case OP_ADD: add("    s%u = addn(%s, %s);\n", dst, x.c_str(), y.c_str()); break;
+            case OP_SUB: add("    s%u = subn(%s, %s);\n", dst, x.c_str(), y.c_str()); break;
+            case OP_MUL: add("    s%u = mul_i(%s, %s);\n", dst, x.c_str(), y.c_str()); break;
+            case OP_SQR: add("    s%u = fu_sqr<UF>(%s);\n", dst, x.c_str()); break;
+            case OP_DBL: add("    s%u = fu_norm(fu_dbl(%s));\n", dst, x.c_str()); break;
+            case OP_NEG: add("    s%u = fu_norm(fu_neg(%s));\n", dst, x.c_str()); break;
+            case OP_FMA: add("    s%u = addn(mul_i(s%u, %s), %s);\n", dst, dst, y.c_str(), x.c_str()); break;
+            default: add("    s%u = %s;\n", dst, x.c_str());  // OP_MOV
+        }
+        if (o.op & OP_REDUCE_FLAG) add("    s%u = mul_i(s%u, fu_one_i<UF>());\n", dst, dst);
+        // one scheduling region per operation: the whole program as ONE basic block (tens of thousands of instructions) costs the
+        // scheduler and the register allocator minutes and buys nothing -- a field multiplication already fills the pipeline
+        if (sched_barriers) src += "    __builtin_amdgcn_sched_barrier(0);\n";
+    }
+    switch (P.result.kind) {  // prog_result_e
+        case H2HIP_VS_FIXED: case H2HIP_VS_ADVICE: case H2HIP_VS_INSTANCE:
+            add("    values[idx] = %c%u[r%u];\n", col_name[P.result.kind - H2HIP_VS_FIXED], P.result.a, P.result.b);
+            break;
+        case H2HIP_VS_PREVIOUS: src += "    (void)prev_e;\n"; break;
+        case EVALH_VS_ZERO: src += "    values[idx] = fe_zero<FrP>();\n"; break;
+        default: add("    values[idx] = out_e(%s);\n", operand(P.result).c_str());
+    }
+    src += "}\n";
+    return src;
+}
+
+static uint64_t fnv1a64(const std::string& s) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (unsigned char ch : s) {
+        h ^= ch;
+        h *= 0x100000001b3ull;
+    }
+    return h;
+}
+
+struct RtcEntry {
+    std::mutex m;
+    int state = 0;  // 0 compiling, 1 ready, 2 failed
+    std::vector<char> code;
+    std::string log;
+    std::thread th;
+    double compile_s = 0.0;
+};
+static std::map<uint64_t, std::shared_ptr<RtcEntry>> g_rtc;
+
+static std::string rtc_cache_path(uint64_t key) {
+    const char* dir = getenv("HALO2_HIP_CACHE_DIR");
+    if (!dir || !*dir) return std::string();
+    char name[64];
+    snprintf(name, sizeof(name), "/evalh_gates_%016llx_gfx950.co", (unsigned long long)key);
+    return std::string(dir) + name;
+}
+
+static void rtc_compile(std::shared_ptr<RtcEntry> e, std::string src, uint64_t key) {
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<char> code;
+    std::string log;
+    bool ok = false;
+    const std::string path = rtc_cache_path(key);
+    if (!path.empty()) {  // a code object an earlier process left for this very source
+        if (FILE* f = fopen(path.c_str(), "rb")) {
+            fseek(f, 0, SEEK_END);
+            const long sz = ftell(f);
+            fseek(f, 0, SEEK_SET);
+            if (sz > 0) {
+                code.resize((size_t)sz);
+                ok = fread(code.data(), 1, (size_t)sz, f) == (size_t)sz;
+            }
+            fclose(f);
+            if (ok) g_rtc_stats.disk_hits++;
+        }
+    }
+    if (!ok) {
+        hiprtcProgram prog = nullptr;
+        hiprtcResult r = g_hiprtc.Create(&prog, src.c_str(), "evalh_gates_gen.hip", H2_RTC_N_HEADERS, H2_RTC_HEADER_TEXT, H2_RTC_HEADER_NAMES);
+        if (r == HIPRTC_SUCCESS) {
+            const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+            r = g_hiprtc.Compile(prog, 3, opts);
+            size_t ls = 0;
+            if (g_hiprtc.GetLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
+                log.resize(ls);
+                (void)g_hiprtc.GetLog(prog, &log[0]);
+            }
+            size_t cs = 0;
+            if (r == HIPRTC_SUCCESS && g_hiprtc.GetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs) {
+                code.resize(cs);
+                ok = g_hiprtc.GetCode(prog, code.data()) == HIPRTC_SUCCESS;
+            }
+            (void)g_hiprtc.Destroy(&prog);
+        }
+        if (ok && !path.empty()) {  // write-then-rename: a concurrent reader sees the whole file or none
+            const std::string tmp = path + ".tmp" + std::to_string((unsigned long long)key ^ (unsigned long long)(uintptr_t)&code);
+            if (FILE* f = fopen(tmp.c_str(), "wb")) {
+                const bool w = fwrite(code.data(), 1, code.size(), f) == code.size();
+                fclose(f);
+                if (!w || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
+            }
+        }
+    }
+    std::lock_guard<std::mutex> lk(e->m);
+    e->compile_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    e->log.swap(log);
+    if (ok) {
+        e->code.swap(code);
+        e->state = 1;
+        g_rtc_stats.compiled++;
+    } else {
+        e->state = 2;
+        g_rtc_stats.failed++;
+    }
+}
+
+// test / tooling hook, no GPU needed: the source a graph's program is emitted as, and (compile != 0) what hiprtc makes of it
+int evalh_debug_codegen_source(const h2hip_graph* g, char* buf, size_t cap, size_t* len, int compile, double* seconds, size_t* code_bytes) {
+    if (!g || !len) {
+        set_error("evaluate_h: null argument");
+        return 1;
+    }
+    h2hip_evalh_desc any;
+    memset(&any, 0, sizeof(any));
+    any.n_fixed = any.n_advice = any.n_instance = any.n_challenges = 0xffffffffu;
+    if (graph_validate(*g, any, "given")) return 1;
+    const Program P = compile_graph(*g);
+    const std::string src = gen_source(*g, P);
+    *len = src.size();
+    if (buf && cap) {
+        const size_t m = src.size() < cap - 1 ? src.size() : cap - 1;
+        memcpy(buf, src.data(), m);
+        buf[m] = 0;
+    }
+    if (!compile) return 0;
+    {
+        std::lock_guard<std::mutex> lk(g_rtc_mu);
+        if (!hiprtc_load()) {
+            set_error("evaluate_h: libhiprtc.so could not be loaded");
+            return 2;
+        }
+    }
+    auto e = std::make_shared<RtcEntry>();
+    rtc_compile(e, src, fnv1a64(src));
+    if (seconds) *seconds = e->compile_s;
+    if (code_bytes) *code_bytes = e->code.size();
+    if (e->state != 1) {
+        set_error("evaluate_h: hiprtc rejected the generated kernel: %.300s", e->log.c_str());
+        return 2;
+    }
+    return 0;
+}
+
+// join the compile threads (h2hip_shutdown, after the contexts are released); the compiled code stays cached for a later init
+void evalh_rtc_shutdown() {
+    std::lock_guard<std::mutex> lk(g_rtc_mu);
+    for (auto& kv : g_rtc)
+        if (kv.second->th.joinable()) kv.second->th.join();
+}
+
+void evalh_modules_free(Ctx* c) {
+    for (auto& kv : c->evalh_mods)
+        if (kv.second.first) (void)hipModuleUnload((hipModule_t)kv.second.first);
+    c->evalh_mods.clear();
+}
+
+// the generated kernel for this program on this device, or nullptr: not wanted, not compiled yet (the interpreter serves this
+// call), or not compilable (it serves every call)
+static hipFunction_t gates_kernel_for(Ctx* c, const h2hip_graph& g, const Program& P) {
+    if (g_evalh_codegen <= 0 || P.ops.empty() || P.ops.size() > g_evalh_codegen_max_ops || P.n_slots > EVALH_CODEGEN_MAX_SLOTS) return nullptr;
+    std::string src = gen_source(g, P);
+    const uint64_t key = fnv1a64(src);
+    auto hit = c->evalh_mods.find(key);
+    if (hit != c->evalh_mods.end()) return (hipFunction_t)hit->second.second;
+    std::shared_ptr<RtcEntry> e;
+    bool mine = false;  // this call created the entry and compiles it inline
+    {
+        std::lock_guard<std::mutex> lk(g_rtc_mu);
+        auto it = g_rtc.find(key);
+        if (it != g_rtc.end()) {
+            e = it->second;
+            if (g_evalh_codegen >= 2 && e->th.joinable()) e->th.join();  // tests: wait for a compile another call started
+        } else {
+            if (!hiprtc_load()) return nullptr;
+            try {
+                e = std::make_shared<RtcEntry>();
+                g_rtc[key] = e;
+            } catch (...) {
+                return nullptr;
+            }
+            mine = true;
+            if (g_evalh_codegen == 1) {
+                try {
+                    e->th = std::thread(rtc_compile, e, src, key);
+                    mine = false;
+                } catch (...) {  // no thread to be had: compile inline
+                }
+            }
+        }
+    }
+    if (mine) rtc_compile(e, src, key);
+    std::lock_guard<std::mutex> lk(e->m);
+    if (e->state != 1) return nullptr;
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    if (hipModuleLoadData(&mod, e->code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, "evalh_gates_gen") != hipSuccess) {
+        (void)hipGetLastError();
+        if (mod) (void)hipModuleUnload(mod);
+        c->evalh_mods[key] = {nullptr, nullptr};  // do not try again on this device
+        return nullptr;
+    }
+    c->evalh_mods[key] = {(void*)mod, (void*)fn};
+    return fn;
+}
+
 struct Arena {
     char* base = nullptr;
     size_t off = 0, cap = 0;
@@ -598,6 +990,29 @@ static int slot_plan(uint32_t n_slots, size_t size, SlotPlan* out) {
 void evalh_debug_set_max_local_slots(uint32_t v) { g_evalh_max_local_slots = v; }
 static size_t g_evalh_lookup_group_bytes = (size_t)2 << 30;  // HBM one group of lookup cosets may take (tests shrink it to force several groups)
 void evalh_debug_set_lookup_group_bytes(uint64_t v) { g_evalh_lookup_group_bytes = v ? (size_t)v : (size_t)2 << 30; }
+
+// field multiplications one row of the compiled program performs (products, squares, Horner steps, inserted reductions, and the
+// exact reduction of the stored value): the numerator of the gates kernel's valu_roofline in bench.py
+int evalh_debug_program_muls(const h2hip_graph* g, uint32_t* n_mul) {
+    if (!g || !n_mul) {
+        set_error("evaluate_h: null argument");
+        return 1;
+    }
+    h2hip_evalh_desc any;
+    memset(&any, 0, sizeof(any));
+    any.n_fixed = any.n_advice = any.n_instance = any.n_challenges = 0xffffffffu;
+    if (graph_validate(*g, any, "given")) return 1;
+    const Program P = compile_graph(*g);
+    uint32_t m = 0;
+    for (const DevOp& o : P.ops) {
+        const uint32_t k = o.op & 0xff;
+        if (k == OP_MUL || k == OP_SQR || k == OP_FMA) m++;
+        if (o.op & OP_REDUCE_FLAG) m++;
+    }
+    if (P.result.kind == H2HIP_VS_INTERMEDIATE || P.result.kind <= H2HIP_VS_CONSTANT || (P.result.kind >= H2HIP_VS_CHALLENGE && P.result.kind <= H2HIP_VS_Y)) m++;
+    *n_mul = m;
+    return 0;
+}
 
 int evalh_debug_compile_stats(const h2hip_graph* g, uint32_t* n_ops, uint32_t* n_slots) {
     if (!g || !n_ops || !n_slots) {
@@ -854,11 +1269,21 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
     sc.in3[1] = load_fe(d->g_coset);
     sc.in3[2] = load_fe(d->g_coset_inv);
     sc.in_len = n;
+    int t_c = c->timer_begin("evalh_cosets", s);
     if ((rc = ntt_device_batch(c, poly_dst.data(), poly_src.data(), poly_dst.size(), ext_omega, ek, &sc, s))) return rc;
+    c->timer_end(t_c, s);
     const dim3 grid((uint32_t)((size + 255) / 256)), block(256);
 
-    // ---- custom gates (:334-360)
-    {
+    // ---- custom gates (:334-360): the kernel generated for this circuit once it is compiled, the interpreter until then
+    int t_g = c->timer_begin("evalh_gates", s);
+    hipFunction_t gen = gates_plan.tier != 0 ? gates_kernel_for(c, d->custom_gates, gates_prog) : nullptr;
+    if (gen) {
+        Fe* vals = d_values;
+        void* args[] = {(void*)&cols, (void*)&vals};
+        H2_CHECK(hipModuleLaunchKernel(gen, (uint32_t)((size + 255) / 256), 1, 1, 256, 1, 1, 0, s, args, nullptr));
+        g_rtc_stats.launches++;
+    } else {
+        g_rtc_stats.interpreted++;
         const dim3 g(gates_plan.lanes / 256);
         switch (gates_plan.tier) {
             case 4: hipLaunchKernelGGL(evalh_gates_kernel<4>, g, block, 4 * 9 * 256 * 4, s, gd, cols, d_values, gws, gates_plan.lanes); break;
@@ -870,15 +1295,19 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         }
     }
     H2_CHECK(hipGetLastError());
+    c->timer_end(t_g, s);
 
     // ---- permutations (:362-441)
     if (d->n_perm_sets) {
+        int t_p = c->timer_begin("evalh_perm", s);
         hipLaunchKernelGGL(evalh_perm_kernel, grid, block, 0, s, pd, cols, d_values);
         H2_CHECK(hipGetLastError());
+        c->timer_end(t_p, s);
     }
 
     // ---- lookups (:443-518): the three cosets of a lookup are formed in groups (the first group with the columns above), used, and
     //      the group's buffers reused
+    int t_l = d->n_lookups ? c->timer_begin("evalh_lookups", s) : -1;
     for (uint32_t i = 0; i < d->n_lookups; i++) {
         const size_t gi = i % lk_group;
         if (gi == 0 && i) {  // the next group's cosets
@@ -905,6 +1334,7 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         }
         H2_CHECK(hipGetLastError());
     }
+    c->timer_end(t_l, s);
     if ((rc = guard.release())) return rc;
     if (dev) return 0;
     H2_CHECK(hipMemcpyAsync(values, d_values, col_bytes, hipMemcpyDeviceToHost, s));

@@ -10,9 +10,24 @@
 // instruction, v_mul_lo/hi_u32, v_add_co/addc, v_lshl_add_u64 at ~4.3-4.7 -- integer multiply
 // is NOT quarter-rate on gfx950, so the cost of a modular multiply is its instruction count.
 #pragma once
+#if defined(__HIPCC_RTC__)
+// compiled at run time by hiprtc (evalh.hip's per-circuit gates kernel): the runtime's device declarations and the fixed-width
+// integer types are part of hiprtc's built-in prelude, and no system header can be found from there
+#define H2_HD __device__ __forceinline__
+typedef unsigned char uint8_t;
+typedef unsigned short uint16_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+typedef unsigned long size_t;
+typedef unsigned long uintptr_t;
+#else
 #include <stdint.h>
+#endif
 
-#if defined(__HIPCC__)
+#if defined(__HIPCC_RTC__)
+#elif defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define H2_HD __host__ __device__ __forceinline__
 #else

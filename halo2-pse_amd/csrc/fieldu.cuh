@@ -20,7 +20,16 @@
 //   (a*b/2^261, a*b/2^261 + p).  fu_add / fu_sub are limb-wise on int32: callers keep |l| < 2^31.
 //   fu_norm propagates carries: limbs 0..7 back in [0, 2^29), value unchanged.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <utility>
+#else
+namespace std {  // hiprtc has no <utility>: the two templates this file uses, on the compiler's builtin
+template <class T, T... I>
+struct integer_sequence {};
+template <class T, T N>
+using make_integer_sequence = __make_integer_seq<integer_sequence, T, N>;
+}  // namespace std
+#endif
 
 #include "field.cuh"
 

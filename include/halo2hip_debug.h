@@ -68,6 +68,17 @@ int h2hip_debug_set_ntt_two_pass_log_j(int v);
 int h2hip_debug_set_evalh_max_local_slots(uint32_t v);
 /* evaluate_h: HBM one group of lookup cosets may take (0 = default 2 GB; the first group is transformed with the advice columns) */
 int h2hip_debug_set_evalh_lookup_group_bytes(uint64_t v);
+/* evaluate_h: field multiplications per row of the program a graph compiles to; needs no GPU */
+int h2hip_debug_evalh_program_muls(const h2hip_graph* g, uint32_t* n_mul);
+/* evaluate_h: the per-circuit gates kernel (hiprtc): 0 off, 1 compiled on a background thread while the interpreter serves (default;
+ * HALO2_HIP_EVALH_CODEGEN), 2 compiled inline; + 16: without the fusion of two products into one reduction; max_ops: programs with more operations (or more than 48
+ * values alive at once) stay with the interpreter (0 = default 1200) */
+int h2hip_debug_set_evalh_codegen(int mode, uint32_t max_ops);
+/* the HIP source a graph's program is emitted as (buf may be NULL: *len alone), and with compile != 0 what hiprtc makes of it for gfx950
+ * (seconds, bytes of code object); needs no GPU.  Returns 0, 1 (malformed graph) or 2 (hiprtc missing / rejected the source). */
+int h2hip_debug_evalh_codegen_source(const h2hip_graph* g, char* buf, size_t cap, size_t* len, int compile, double* seconds, size_t* code_bytes);
+/* out: programs compiled, compilations failed, launches of a generated kernel, launches of the interpreter, disk-cache hits */
+int h2hip_debug_evalh_codegen_stats(uint64_t out[5]);
 /* evaluate_h: compile a graph as the engine would and report the program's size; needs no GPU */
 int h2hip_debug_evalh_compile_stats(const h2hip_graph* g, uint32_t* n_ops, uint32_t* n_slots);
 

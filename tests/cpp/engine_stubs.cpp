@@ -39,6 +39,12 @@ void ntt_twiddles_free(Ctx*) {}
 void evalh_debug_set_max_local_slots(uint32_t) {}
 void evalh_debug_set_lookup_group_bytes(uint64_t) {}
 int evalh_debug_compile_stats(const h2hip_graph*, uint32_t*, uint32_t*) { return 0; }
+int evalh_debug_program_muls(const h2hip_graph*, uint32_t*) { return 0; }
+void evalh_debug_set_codegen(int, uint32_t) {}
+void evalh_debug_codegen_stats(uint64_t out[5]) { memset(out, 0, 5 * sizeof(uint64_t)); }
+int evalh_debug_codegen_source(const h2hip_graph*, char*, size_t, size_t*, int, double*, size_t*) { return 0; }
+void evalh_modules_free(Ctx*) {}
+void evalh_rtc_shutdown() {}
 int evaluate_h_validate(const h2hip_evalh_desc*, const void*) { return 0; }
 int evaluate_h_host(Ctx*, const h2hip_evalh_desc*, uint64_t*, bool, hipStream_t) { return 0; }
 int g_to_lagrange_device(Ctx*, const Affine*, uint32_t, Affine*, hipStream_t) { return 0; }

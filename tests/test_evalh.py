@@ -100,9 +100,31 @@ def _random_case(oracle, k, seed, n_gates=3):
     return case, col(size, 99)
 
 
+@pytest.fixture(params=["interpreter", "generated"])
+def gates_kernel(request, h2):
+    """run a GPU test twice: custom gates through the byte-code interpreter (code generation off) and through the kernel generated for
+    the circuit and compiled inline by hiprtc (mode 2) -- the counters must show that the generated kernel is the one that ran"""
+    L = h2.lib()
+    h2.init()
+    before = (ctypes.c_uint64 * 5)()
+    L.h2hip_debug_evalh_codegen_stats(before)
+    L.h2hip_debug_set_evalh_codegen(ctypes.c_int(0 if request.param == "interpreter" else 2), ctypes.c_uint32(0))
+    mode = {"kind": request.param, "expect_generated": request.param == "generated"}  # a test whose program is beyond the generator's limits clears the flag
+    yield mode
+    after = (ctypes.c_uint64 * 5)()
+    L.h2hip_debug_evalh_codegen_stats(after)
+    L.h2hip_debug_set_evalh_codegen(ctypes.c_int(1), ctypes.c_uint32(0))
+    if request.param == "generated":
+        assert after[1] == before[1], "hiprtc rejected a generated kernel: " + L.h2hip_last_error().decode()
+        if mode["expect_generated"]:
+            assert after[2] > before[2], "the generated kernel never ran"
+    else:
+        assert after[2] == before[2]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["k3", "k4"])
-def test_gpu_evaluate_h_golden(h2, oracle, evalh_golden, tag):
+def test_gpu_evaluate_h_golden(h2, oracle, evalh_golden, tag, gates_kernel):
     case, vin, vout = load_case(evalh_golden, tag)
     if tag == "k4":  # scalars at addresses that are only 8-byte aligned, as inside a Rust struct
         for f in ("extended_omega", "g_coset", "g_coset_inv", "zeta", "delta", "y", "beta", "gamma", "theta"):
@@ -120,7 +142,7 @@ def test_gpu_evaluate_h_golden(h2, oracle, evalh_golden, tag):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("k", [5, 9, 13])
-def test_gpu_evaluate_h_vs_oracle(h2, oracle, k):
+def test_gpu_evaluate_h_vs_oracle(h2, oracle, k, gates_kernel):
     """bigger synthetic systems (instance column, challenges, mixed permutation column kinds, two lookups, three
     permutation sets with a ragged last chunk): GPU == oracle, limb for limb"""
     case, vin = _random_case(oracle, k, seed=k)
@@ -187,7 +209,7 @@ def test_evaluator_new_builds_the_golden_graphs(evalh_golden):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("group_bytes", [0, 1])
-def test_gpu_evaluate_h_device_resident(h2, oracle, group_bytes):
+def test_gpu_evaluate_h_device_resident(h2, oracle, group_bytes, gates_kernel):
     """h2hip_evaluate_h_bn254_device: every column already in HBM (torch tensors), values folded in place on the current
     stream, inputs untouched; equal to the oracle and to the host-pointer entry point.  group_bytes = 1: one lookup per group
     of coset buffers (the second lookup's cosets are formed after the first lookup's kernel, in the reused buffers) instead of
@@ -284,7 +306,7 @@ def test_compiled_program_is_compact(h2, oracle):
 
 
 @pytest.mark.gpu
-def test_gpu_evaluate_h_large_graph(h2, oracle):
+def test_gpu_evaluate_h_large_graph(h2, oracle, gates_kernel):
     """more intermediates than any per-lane scratch tier holds one-to-one (the reference's Vec is unbounded): slots are
     shared by lifetime"""
     case, vin = _random_case(oracle, 8, seed=21, n_gates=40)
@@ -371,6 +393,7 @@ def test_oracle_evaluate_h_degenerate_systems(oracle, variant):
     elif variant == "empty_graph":
         case = _strip(case, perm=False, lookups=False)
         case["custom"] = flatten_graph(GraphEvaluator())
+        gates_kernel["expect_generated"] = False  # no operations: nothing to generate, the interpreter's empty loop stores the zero
         want = np.zeros_like(vin)
     else:
         case = _strip(case, perm=variant not in ("no_perm", "gates_only"), lookups=variant not in ("no_lookups", "gates_only"))
@@ -386,7 +409,7 @@ def test_oracle_evaluate_h_degenerate_systems(oracle, variant):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", ["no_perm", "no_lookups", "gates_only", "empty_graph", "horner_without_parts"])
-def test_gpu_evaluate_h_degenerate_systems(h2, oracle, variant):
+def test_gpu_evaluate_h_degenerate_systems(h2, oracle, variant, gates_kernel):
     from evalh_util import GraphEvaluator, custom_gates_graph, flatten_graph
     case, vin = _random_case(oracle, 6, seed=10)
     if variant == "horner_without_parts":
@@ -395,6 +418,7 @@ def test_gpu_evaluate_h_degenerate_systems(h2, oracle, variant):
     elif variant == "empty_graph":
         case = _strip(case, perm=False, lookups=False)
         case["custom"] = flatten_graph(GraphEvaluator())
+        gates_kernel["expect_generated"] = False  # no operations: nothing to generate, the interpreter's empty loop stores the zero
     else:
         case = _strip(case, perm=variant not in ("no_perm", "gates_only"), lookups=variant not in ("no_lookups", "gates_only"))
     h = DescHolder(case)
@@ -407,7 +431,7 @@ def test_gpu_evaluate_h_degenerate_systems(h2, oracle, variant):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_live", [2, 6, 12, 40, 100])
-def test_gpu_evaluate_h_every_slot_tier(h2, oracle, n_live):
+def test_gpu_evaluate_h_every_slot_tier(h2, oracle, n_live, gates_kernel):
     """slots live in registers (up to 4 / 8), per-lane scratch (16 / 64 / 256) or the global workspace: one graph per tier,
     each with n_live products alive at once, against the oracle"""
     from evalh_util import flatten_graph
@@ -415,6 +439,8 @@ def test_gpu_evaluate_h_every_slot_tier(h2, oracle, n_live):
     case["custom"] = flatten_graph(_many_live_graph(n_live))
     _, n_slots = _compile_stats(h2, case["custom"])
     assert n_live <= n_slots <= n_live + 2
+    if n_slots > 48:
+        gates_kernel["expect_generated"] = False  # more live values than the generator takes on: the interpreter serves them
     h = DescHolder(case)
     want = vin.copy()
     assert oracle.lib().oracle_evaluate_h(h.byref(), want.ctypes.data_as(ctypes.c_void_p)) == 0
@@ -468,6 +494,44 @@ def _random_graph(rng, n_calcs, n_adv=5, n_fix=6):
     return g
 
 
+def _codegen(h2, graph_dict, compile_it=True):
+    """(source, seconds, code bytes) of the per-circuit gates kernel for a flattened graph: host-only, hiprtc cross-compiles gfx950 without a GPU"""
+    from evalh_util import DescHolder as DH
+    holder = DH.__new__(DH)
+    holder.keep = []
+    G = holder._graph(graph_dict)
+    L = h2.lib()
+    n = ctypes.c_size_t()
+    assert L.h2hip_debug_evalh_codegen_source(ctypes.byref(G), None, ctypes.c_size_t(0), ctypes.byref(n), ctypes.c_int(0), None, None) == 0
+    buf = ctypes.create_string_buffer(n.value + 1)
+    secs, size = ctypes.c_double(), ctypes.c_size_t()
+    rc = L.h2hip_debug_evalh_codegen_source(ctypes.byref(G), buf, ctypes.c_size_t(n.value + 1), ctypes.byref(n), ctypes.c_int(1 if compile_it else 0),
+                                            ctypes.byref(secs), ctypes.byref(size))
+    assert rc == 0, L.h2hip_last_error().decode()
+    return buf.value.decode(), secs.value, size.value
+
+
+def test_generated_gates_kernel_compiles_for_gfx950(h2, oracle, evalh_golden):
+    """CPU: the straight-line source evalh.hip emits for a circuit's custom gates -- the reference's own example circuit (k = 4 golden
+    graph), a 40-gate system, a graph with 40 values alive at once and random graphs with every operation kind -- is accepted by hiprtc
+    for gfx950 from the embedded headers alone; one statement per program operation."""
+    from evalh_util import flatten_graph
+    case, _, _ = load_case(evalh_golden, "k4")
+    src, secs, size = _codegen(h2, case["custom"])
+    n_ops, n_slots = _compile_stats(h2, case["custom"])
+    assert 'extern "C" __global__ void' in src and "evalh_gates_gen" in src and size > 1000
+    assert sum(1 for ln in src.splitlines() if ln.startswith("    s") and " = " in ln) >= n_ops
+    big, _ = _random_case(oracle, 5, seed=5, n_gates=40)
+    src, secs, size = _codegen(h2, big["custom"])
+    assert size > 1000 and secs < 120
+    _, _, size = _codegen(h2, flatten_graph(_many_live_graph(40)))
+    assert size > 1000
+    rng = np.random.default_rng(11)
+    for _ in range(4):
+        _, _, size = _codegen(h2, flatten_graph(_random_graph(rng, int(rng.integers(5, 90)))))
+        assert size > 1000
+
+
 def test_compile_survives_random_graphs(h2):
     """host-only: validation + compilation of 200 random graphs neither fails nor needs more slots than intermediates"""
     from evalh_util import flatten_graph
@@ -479,7 +543,7 @@ def test_compile_survives_random_graphs(h2):
 
 
 @pytest.mark.gpu
-def test_gpu_evaluate_h_random_graphs(h2, oracle):
+def test_gpu_evaluate_h_random_graphs(h2, oracle, gates_kernel):
     """40 random graphs (custom gates and one lookup each) against the oracle: exercises Store folding, Horner hoisting, dead
     code, slot reuse and the inserted magnitude reductions far from the shapes add_expression produces"""
     from evalh_util import flatten_graph

@@ -491,6 +491,69 @@ def test_two_device_contexts_shard_fold_bit_exact():
     assert out["pinned_points"] == 1 << 16
 
 
+_MULTI3 = r"""
+import ctypes, json, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from conftest import load_pkg
+from oracle import oracle
+h2 = load_pkg()
+out = {}
+h2.init([0, 0, 0])
+out["devices"] = h2.num_devices()
+aff = lambda x: h2.g1_to_affine(x).tolist()
+orc = lambda s_, b_: oracle.g1_to_affine(oracle.best_multiexp(s_, b_, 8)).tolist()
+# (1) a pin whose shares are uneven: n not divisible by the device count
+n = (1 << 16) + 5
+sc = oracle.gen_scalars(0x5EED0001, n, num_threads=8)
+bs = oracle.gen_points(0x5EED0002, n, num_threads=8)
+h2.bases_pin(bs)
+out["pinned_points"] = h2.bases_pinned_info(bs)[0]
+out["uneven_equal"] = aff(h2.best_multiexp(sc, bs)) == orc(sc, bs)
+# (2) polynomials shorter than the pinned SRS: only the first device's share / ending inside the second's -- trailing devices idle
+for name, m in (("prefix_first_share", n // 3 - 7), ("prefix_two_shares", n // 3 + 1000), ("prefix_all_but_one", n - 1), ("prefix_tiny", 2000)):
+    out[name] = aff(h2.best_multiexp(sc[:m], bs[:m])) == orc(sc[:m], bs[:m])
+cols = [oracle.gen_scalars(50 + j, n // 2, num_threads=8) for j in range(4)]
+got = h2.best_multiexp_batch(cols, bs[:n // 2])
+out["batch_prefix_equal"] = all(aff(got[j]) == orc(cols[j], bs[:n // 2]) for j in range(4))
+h2.bases_unpin(bs)
+# (3) BASELINE.json configs[3]'s shape in small: ONE fixed-base MSM sharded over every device of the engine, gather asked over RCCL.
+# The same card thrice cannot form a communicator: the call must fall back to the host fold and still be right.
+n4 = 1 << 18
+sc4 = oracle.gen_scalars(0x5EED0011, n4, num_threads=8)
+bs4 = oracle.gen_points(0x5EED0012, n4, num_threads=8)
+h2.bases_pin(bs4)
+out["config4_shape_equal"] = aff(h2.best_multiexp(sc4, bs4)) == orc(sc4, bs4)
+h2.bases_unpin(bs4)
+# (4) host-pointer batched transforms dealt over three contexts (7 columns: shares of 2 / 2 / 3), each share its own pipeline
+k = 12
+dom = h2.EvaluationDomain.new(4, k)
+od, _ = oracle.domain_new(4, k)
+cols_h = [oracle.gen_scalars(900 + j, 1 << k, num_threads=8) for j in range(7)]
+out["host_batch_ifft_equal"] = all(np.array_equal(g_, oracle.lagrange_to_coeff(od, c_, 4)) for g_, c_ in zip(dom.lagrange_to_coeff_batch(cols_h), cols_h))
+out["host_batch_coset_equal"] = all(np.array_equal(g_, oracle.coeff_to_extended(od, c_.copy(), 4)) for g_, c_ in zip(dom.coeff_to_extended_batch(cols_h), cols_h))
+out["host_batch_two_columns"] = all(np.array_equal(g_, oracle.lagrange_to_coeff(od, c_, 4)) for g_, c_ in zip(dom.lagrange_to_coeff_batch(cols_h[:2]), cols_h[:2]))
+h2.shutdown()
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_three_device_contexts_uneven_shares_idle_devices_and_rccl_fallback():
+    """the multi-device engine has only ever run as rehearsals on one card, so the rehearsal covers the shapes an
+    8-GPU node will produce: a pin whose shares are uneven (n not divisible by N), polynomials shorter than the pinned SRS (trailing
+    devices idle), config 4's shape (one fixed-base MSM over every device) with HALO2_HIP_GATHER=rccl falling back cleanly where
+    ncclCommInitAll refuses, and the host-pointer batched transforms dealt over the devices."""
+    env = dict(os.environ, HALO2_HIP_ALLOW_DUPLICATE_DEVICES="1", HALO2_HIP_MULTI_GPU_MIN_N="1024", HALO2_HIP_GATHER="rccl")
+    r = subprocess.run([sys.executable, "-c", _MULTI3 % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][len("RESULT "):])
+    assert out["devices"] == 3 and out["pinned_points"] == (1 << 16) + 5
+    for key, val in out.items():
+        if key not in ("devices", "pinned_points"):
+            assert val is True, (key, out)
+
+
 def test_env_device_list_and_thresholds():
     code = r"""
 import os, sys

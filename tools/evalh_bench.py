@@ -124,15 +124,63 @@ def bench(args):
             res["match"] = bool(np.array_equal(host(d_values), want))
             assert res["match"], "GPU evaluate_h differs from the oracle"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ts = []
-        for _ in range(args.iters):
-            e0.record()
-            call()
-            e1.record()
+
+        def timed():
+            ts = []
+            for _ in range(args.iters):
+                e0.record()
+                call()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            return float(np.median(ts))
+
+        def stages():  # per-stage HIP-event times of the same call (their records put ~10 us of gap on the stream each)
+            h2.profile_enable(True)
+            h2.profile_reset()
+            for _ in range(3):
+                call()
             torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1))
-        res["gpu_ms"] = float(np.median(ts))
+            h2.profile_enable(False)
+            st = {}
+            for name in ("evalh_cosets", "evalh_gates", "evalh_perm", "evalh_lookups"):
+                tot, cnt = h2.profile_get(name)
+                st[name] = tot / cnt if cnt else None
+            return st
+
+        # custom gates through the byte-code interpreter, then through the kernel generated for this circuit (compiled inline by hiprtc)
+        L.h2hip_debug_set_evalh_codegen(ctypes.c_int(0), ctypes.c_uint32(0))
+        call()
+        res["interpreter"] = {"gpu_ms": timed(), "stage_ms": stages()}
+        stats0 = (ctypes.c_uint64 * 5)()
+        L.h2hip_debug_evalh_codegen_stats(stats0)
+        L.h2hip_debug_set_evalh_codegen(ctypes.c_int(2), ctypes.c_uint32(0))
+        t0 = time.perf_counter()
+        call()
+        torch.cuda.synchronize()
+        first_call_s = time.perf_counter() - t0
+        stats1 = (ctypes.c_uint64 * 5)()
+        L.h2hip_debug_evalh_codegen_stats(stats1)
+        generated = stats1[2] > stats0[2]
+        res["gpu_ms"] = timed()
+        res["stage_ms"] = stages()
+        res["gates_kernel"] = "generated per circuit (hiprtc)" if generated else "interpreter (the program is beyond the generator's limits, or hiprtc is missing)"
+        res["first_call_with_inline_compile_s"] = first_call_s
+        if check or time_cpu:
+            L.h2hip_debug_set_evalh_codegen(ctypes.c_int(2), ctypes.c_uint32(0))
+            d_values.copy_(v0)
+            call()
+            torch.cuda.synchronize()
+            res["match_generated"] = bool(np.array_equal(host(d_values), want))
+            assert res["match_generated"], "GPU evaluate_h (generated gates kernel) differs from the oracle"
+        L.h2hip_debug_set_evalh_codegen(ctypes.c_int(1), ctypes.c_uint32(0))
         res["rows_per_s"] = size / (res["gpu_ms"] * 1e-3)
+        # the gates kernel against the multiplier: field multiplications per row of the compiled program x rows / kernel time
+        n_mul = ctypes.c_uint32()
+        if L.h2hip_debug_evalh_program_muls(ctypes.byref(hd.desc.custom_gates), ctypes.byref(n_mul)) == 0 and res["stage_ms"].get("evalh_gates"):
+            gmul = n_mul.value * size / (res["stage_ms"]["evalh_gates"] * 1e-3) / 1e9
+            res["gates_valu_roofline"] = {"bound": "valu-int", "kernel": "evalh_gates_gen" if generated else "evalh_gates_kernel", "field_mul_per_row": n_mul.value,
+                                          "achieved": gmul, "peak": 179.0, "unit": "Gmul/s", "frac": gmul / 179.0}
         return res
 
     if args.check_k:
