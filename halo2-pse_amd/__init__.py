@@ -169,6 +169,12 @@ def g_to_lagrange(g, k):
     return out
 
 
+def best_fft_g1(a_xyz, omega, log_n):
+    """halo2_proofs::arithmetic::best_fft for G = bn256::G1 (arithmetic.rs:171-234): in place on (2^log_n, 12) Jacobian points"""
+    assert a_xyz.dtype == np.uint64 and a_xyz.flags["C_CONTIGUOUS"] and a_xyz.shape == (1 << log_n, 12)
+    _check(lib().h2hip_fft_bn254_g1(_p(a_xyz), _p(_fe(omega)), ctypes.c_uint32(log_n)), "h2hip_fft_bn254_g1")
+
+
 def g1_to_affine(xyz):
     xyz = np.ascontiguousarray(xyz, dtype=np.uint64).reshape(12)
     out = np.zeros(8, dtype=np.uint64)

@@ -2087,6 +2087,36 @@ int h2hip_g_to_lagrange_bn254(const uint64_t* g_xy, uint32_t k, uint64_t* g_lagr
     return 0;
 }
 
+int h2hip_fft_bn254_g1_device(void* d_a_xyz, const uint64_t omega[4], uint32_t log_n, void* stream) {
+    if (!d_a_xyz || !omega || log_n > 28) {
+        set_error("fft_g1: bad argument");
+        return H2HIP_EINVAL;
+    }
+    if (check_fr(omega, "omega")) return H2HIP_EINVAL;
+    Entry en("h2hip_fft_bn254_g1_device", d_a_xyz);
+    if (en.rc) return en.rc;
+    return fft_g1_device(en.c, (Jac*)d_a_xyz, fe_from_u64x4(omega), log_n, (hipStream_t)stream);
+}
+
+int h2hip_fft_bn254_g1(uint64_t* a_xyz, const uint64_t omega[4], uint32_t log_n) {
+    if (!a_xyz || !omega || log_n > 28) {
+        set_error("fft_g1: bad argument");
+        return H2HIP_EINVAL;
+    }
+    if (check_fr(omega, "omega")) return H2HIP_EINVAL;
+    Entry en("h2hip_fft_bn254_g1");
+    if (en.rc) return en.rc;
+    Ctx* c = en.c;
+    const size_t bytes = sizeof(Jac) << log_n;
+    int rc = c->ntt_io.ensure(bytes);
+    if (rc) return rc;
+    H2_CHECK(hipMemcpyAsync(c->ntt_io.p, a_xyz, bytes, hipMemcpyHostToDevice, c->stream));
+    if ((rc = fft_g1_device(c, (Jac*)c->ntt_io.p, fe_from_u64x4(omega), log_n, c->stream))) return rc;
+    H2_CHECK(hipMemcpyAsync(a_xyz, c->ntt_io.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    H2_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int h2hip_kzg_setup_bn254_device(uint32_t k, const uint64_t secret[4], void* d_g_xy, void* d_g_lagrange_xy, void* stream) {
     if (!secret || !d_g_xy || !d_g_lagrange_xy) {
         set_error("kzg_setup: null argument");

@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) ec_normalize_kernel(const XYZZ* in, Affin
     }
 }
 
-__global__ void __launch_bounds__(256) ecfft_twiddle_kernel(GlvScalar* tw, uint64_t count, Fe omega_inv) {
+__global__ void __launch_bounds__(256) ecfft_twiddle_kernel(GlvScalar* tw, uint64_t count, Fe omega_inv /* the transform's root: omega^-1 for g_to_lagrange */) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= count) return;
     const Fe c = fe_to_canonical<FrP>(fe_pow_u64<FrP>(omega_inv, tid));
@@ -245,12 +245,40 @@ static int normalize_launch(const XYZZ* in, Affine* out, uint64_t n, hipStream_t
 
 int ec_normalize_device(const XYZZ* d_in, Affine* d_out, uint64_t n, hipStream_t s) { return normalize_launch(d_in, d_out, n, s); }
 
-// d_g: n affine points in (read only); d_out: n affine points out.  Queued on s; does not wait.
-int g_to_lagrange_device(Ctx* c, const Affine* d_g, uint32_t k, Affine* d_out, hipStream_t s) {
-    if (k > FrP::S) {
-        set_error("g_to_lagrange: k = %u exceeds the 2-adicity of Fr", k);
-        return 1;
+// Jacobian (x, y, z) -> XYZZ (x, y, z^2, z^3): the form ec_normalize_kernel takes; identity (z = 0) -> zz = zzz = 0
+__global__ void __launch_bounds__(256) jac_to_xyzz_kernel(const Jac* in, XYZZ* out, uint64_t n) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n) return;
+    const Jac p = in[tid];
+    XYZZ o;
+    o.x = p.x;
+    o.y = p.y;
+    o.zz = fe_sqr<FqP>(p.z);
+    o.zzz = fe_mul<FqP>(o.zz, p.z);
+    out[tid] = o;
+}
+
+// affine -> Jacobian with z = 1; identity (0, 0) -> (0, 1, 0), halo2curves' G1::identity()
+__global__ void __launch_bounds__(256) affine_to_jac_kernel(const Affine* in, Jac* out, uint64_t n) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n) return;
+    const Affine a = in[tid];
+    Jac o;
+    if (affine_is_identity(a)) {
+        o.x = fe_zero<FqP>();
+        o.y = fe_one<FqP>();
+        o.z = fe_zero<FqP>();
+    } else {
+        o.x = a.x;
+        o.y = a.y;
+        o.z = fe_one<FqP>();
     }
+    out[tid] = o;
+}
+
+// best_fft with G = G1 (arithmetic.rs:171-234): the layers of the curve-point FFT with twiddles omega^i, then -- scale != nullptr --
+// every point times *scale (g_to_lagrange's 1 / n).  d_in: n affine points (read only), d_out: n affine points.  Queued on s.
+static int ecfft_device(Ctx* c, const Affine* d_in, uint32_t k, Affine* d_out, const Fe& omega, const Fe* scale, hipStream_t s) {
     const uint64_t n = 1ull << k;
     // workspace: XYZZ[n] | twiddles[n / 2]; the affine points of the current layer live in d_out
     const size_t xyzz_bytes = n * sizeof(XYZZ), tw_bytes = (n / 2 + 1) * sizeof(GlvScalar);
@@ -261,19 +289,11 @@ int g_to_lagrange_device(Ctx* c, const Affine* d_g, uint32_t k, Affine* d_out, h
     XYZZ* d_xyzz = (XYZZ*)c->ecfft_ws.p;
     GlvScalar* d_tw = (GlvScalar*)((char*)c->ecfft_ws.p + ((xyzz_bytes + 255) / 256) * 256);
     int tid = c->timer_begin("g_to_lagrange", s);
-    // arithmetic.rs:278-282
-    Fe omega_inv;
-    memcpy(omega_inv.l, FrP::ROOT_OF_UNITY_INV, sizeof(omega_inv.l));  // Montgomery form, as stored
-    for (uint32_t i = k; i < FrP::S; i++) omega_inv = fe_sqr<FrP>(omega_inv);
-    const Fe two_inv = fe_inv<FrP>(fe_from_u64<FrP>(2));
-    const Fe n_inv = fe_to_canonical<FrP>(fe_pow_u64<FrP>(two_inv, k));
-    Scalar256 e_ninv;
-    for (int i = 0; i < 8; i++) e_ninv.w[i] = n_inv.l[i];
     if (n >= 2) {
-        hipLaunchKernelGGL(ecfft_twiddle_kernel, dim3((uint32_t)((n / 2 + 255) / 256)), dim3(256), 0, s, d_tw, n / 2, omega_inv);
+        hipLaunchKernelGGL(ecfft_twiddle_kernel, dim3((uint32_t)((n / 2 + 255) / 256)), dim3(256), 0, s, d_tw, n / 2, omega);
         H2_CHECK(hipGetLastError());
     }
-    const Affine* src = d_g;
+    const Affine* src = d_in;
     for (uint32_t layer = 0; layer < k; layer++) {
         EcfftLayer L = {src, d_xyzz, d_tw, k, layer};
         if (g_ecfft_quad && k <= 14)  // few butterflies per layer (<= 2^13: fewer lanes than SIMD slots even four to a butterfly)
@@ -284,11 +304,61 @@ int g_to_lagrange_device(Ctx* c, const Affine* d_g, uint32_t k, Affine* d_out, h
         if ((rc = normalize_launch(d_xyzz, d_out, n, s))) return rc;
         src = d_out;
     }
-    hipLaunchKernelGGL(ec_scale_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, src, d_xyzz, n, e_ninv);
-    H2_CHECK(hipGetLastError());
-    if ((rc = normalize_launch(d_xyzz, d_out, n, s))) return rc;
+    if (scale) {
+        const Fe sc = fe_to_canonical<FrP>(*scale);
+        Scalar256 e;
+        for (int i = 0; i < 8; i++) e.w[i] = sc.l[i];
+        hipLaunchKernelGGL(ec_scale_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, src, d_xyzz, n, e);
+        H2_CHECK(hipGetLastError());
+        if ((rc = normalize_launch(d_xyzz, d_out, n, s))) return rc;
+    } else if (k == 0 && d_out != d_in) {
+        H2_CHECK(hipMemcpyAsync(d_out, d_in, sizeof(Affine), hipMemcpyDeviceToDevice, s));
+    }
     c->timer_end(tid, s);
     return guard.release();
+}
+
+// d_g: n affine points in (read only); d_out: n affine points out.  Queued on s; does not wait.
+int g_to_lagrange_device(Ctx* c, const Affine* d_g, uint32_t k, Affine* d_out, hipStream_t s) {
+    if (k > FrP::S) {
+        set_error("g_to_lagrange: k = %u exceeds the 2-adicity of Fr", k);
+        return 1;
+    }
+    // arithmetic.rs:278-282
+    Fe omega_inv;
+    memcpy(omega_inv.l, FrP::ROOT_OF_UNITY_INV, sizeof(omega_inv.l));  // Montgomery form, as stored
+    for (uint32_t i = k; i < FrP::S; i++) omega_inv = fe_sqr<FrP>(omega_inv);
+    const Fe two_inv = fe_inv<FrP>(fe_from_u64<FrP>(2));
+    const Fe n_inv = fe_pow_u64<FrP>(two_inv, k);
+    return ecfft_device(c, d_g, k, d_out, omega_inv, &n_inv, s);
+}
+
+// best_fft::<G1>(a, omega, log_n) on device-resident Jacobian points, in place: normalise to affine (batched inversion), the FFT
+// layers, back to Jacobian with z = 1 (identity: z = 0).  Only the group elements are defined by the reference -- its Jacobian
+// coordinates depend on the butterfly order and the thread count.  d_tmp: 2^log_n affine points of scratch.
+int fft_g1_device(Ctx* c, Jac* d_a, const Fe& omega, uint32_t log_n, hipStream_t s) {
+    if (log_n > FrP::S) {
+        set_error("fft_g1: log_n = %u exceeds the 2-adicity of Fr", log_n);
+        return 1;
+    }
+    const uint64_t n = 1ull << log_n;
+    int rc = c->misc.ensure(2 * n * sizeof(Affine) + 256);
+    if (rc) return rc;
+    Affine* d_in = (Affine*)c->misc.p;
+    Affine* d_out = d_in + n;
+    {   // Jacobian -> affine through the FFT's own XYZZ workspace
+        if ((rc = c->ecfft_ws.ensure(n * sizeof(XYZZ) + (n / 2 + 1) * sizeof(GlvScalar) + 256))) return rc;
+        if ((rc = c->ws_acquire(s))) return rc;
+        WsGuard guard(c, s);
+        hipLaunchKernelGGL(jac_to_xyzz_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const Jac*)d_a, (XYZZ*)c->ecfft_ws.p, n);
+        H2_CHECK(hipGetLastError());
+        if ((rc = normalize_launch((const XYZZ*)c->ecfft_ws.p, d_in, n, s))) return rc;
+        if ((rc = guard.release())) return rc;
+    }
+    if ((rc = ecfft_device(c, d_in, log_n, d_out, omega, nullptr, s))) return rc;
+    hipLaunchKernelGGL(affine_to_jac_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const Affine*)d_out, d_a, n);
+    H2_CHECK(hipGetLastError());
+    return 0;
 }
 
 }  // namespace h2

@@ -243,6 +243,7 @@ int scale_periodic_device(Ctx* c, Fe* d_a, uint64_t n, const uint64_t* h_t, uint
 // ecfft.hip
 int g_to_lagrange_device(Ctx* c, const Affine* d_g, uint32_t k, Affine* d_out, hipStream_t s);
 int ec_normalize_device(const XYZZ* d_in, Affine* d_out, uint64_t n, hipStream_t s);  // batched XYZZ -> affine
+int fft_g1_device(Ctx* c, Jac* d_a, const Fe& omega, uint32_t log_n, hipStream_t s);   // best_fft::<G1>, in place on Jacobian points
 
 // setup.hip
 int kzg_setup_device(Ctx* c, uint32_t k, const Fe& s, Affine* d_g, Affine* d_gl, hipStream_t stream);

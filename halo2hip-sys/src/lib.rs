@@ -113,11 +113,18 @@ pub fn try_multiexp_batch<C: CurveAffine>(columns: &[&[C::Scalar]], bases: &[C])
     Some(out.iter().map(|o| unsafe { std::mem::transmute_copy::<[u64; 12], C::Curve>(o) }).collect())
 }
 
-/// `best_fft` on the GPU: true when the engine took the call (`a` then holds the transform).
+/// `best_fft` on the GPU (G = bn256::Fr, or G = bn256::G1 for the curve-point FFT): true when the engine took the call (`a` then holds the transform).
 /// Parity is defined for `omega` of exact order 2^log_n (every in-crate caller); anything else keeps the CPU body.
 pub fn try_fft<G: 'static, S: 'static>(a: &mut [G], omega: &S, log_n: u32) -> bool {
     if log_n >= usize::BITS || a.len() != 1usize << log_n {
         return false;
+    }
+    if is::<G, G1>() {
+        // best_fft over curve points (g_to_lagrange, arithmetic.rs:285): one 254-bit scalar multiplication per butterfly
+        return match fft_guards::<Fr, S>(omega, log_n) {
+            Some(w) => unsafe { ffi::h2hip_fft_bn254_g1(a.as_mut_ptr() as *mut u64, w as *const Fr as *const u64, log_n) == 0 },
+            None => false,
+        };
     }
     match fft_guards::<G, S>(omega, log_n) {
         Some(w) => unsafe { ffi::h2hip_ntt_bn254_fr(a.as_mut_ptr() as *mut u64, w as *const Fr as *const u64, log_n) == 0 },

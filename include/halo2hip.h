@@ -226,6 +226,13 @@ int h2hip_extended_to_coeff_bn254_fr_batch(uint64_t* const* a, size_t count, uin
 int h2hip_g_to_lagrange_bn254(const uint64_t* g_xy, uint32_t k, uint64_t* g_lagrange_xy);
 int h2hip_g_to_lagrange_bn254_device(const void* d_g_xy, uint32_t k, void* d_g_lagrange_xy, void* stream);
 
+/* best_fft with G = bn256::G1 and a caller-supplied omega (arithmetic.rs:171-234; in the crate only g_to_lagrange calls it, :285): in place on
+ * 2^log_n Jacobian points (96 B each, identity z = 0), a[i] <- sum_j [omega^(i*j)] a[j].  omega of exact order 2^log_n; log_n <= 28.  Only
+ * the group elements are defined by the reference (its Jacobian coordinates depend on the butterfly order and rayon's thread count): the
+ * points come back with z = 1 (identity: (0, 1, 0)), compare after normalising. */
+int h2hip_fft_bn254_g1(uint64_t* a_xyz, const uint64_t omega[4], uint32_t log_n);
+int h2hip_fft_bn254_g1_device(void* d_a_xyz, const uint64_t omega[4], uint32_t log_n, void* stream);
+
 /* ---- ParamsKZG::setup: poly/kzg/commitment.rs:61-129, with the secret supplied by the caller (the reference draws it from
  * an rng at :72): g[i] = [s^i] G1 and g_lagrange[i] = [l_i(s)] G1 for i < 2^k, affine, as batch_normalize leaves them.
  * k <= 28; a secret that is a 2^k-th root of unity is H2HIP_EINVAL (the reference panics on the inversion at :100).

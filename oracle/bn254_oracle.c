@@ -851,22 +851,11 @@ static void *g1_layer_thread(void *arg) {
     return NULL;
 }
 
-/* g_to_lagrange (arithmetic.rs:277-301): inverse FFT of the coefficient-basis SRS points, scaled by 1/n, normalised.
- * The butterflies are those of best_fft's iterative form (arithmetic.rs:202-230); its recursive form (:232) performs the
- * same group operations in another order, and only the group elements are defined.  num_threads only splits each layer's
- * blocks over threads (test speed); it does not change the result. */
-int oracle_g_to_lagrange(const g1a *g, uint32_t k, g1a *g_lagrange, int num_threads) {
-    oracle_init();
-    if (k > FR_S) return -1;
+/* best_fft with G = G1 (arithmetic.rs:171-234), iterative form (:202-230), in place on Jacobian points: bit-reversal, the serial
+ * twiddle scan, then the butterfly layers.  The recursive form (:232) performs the same group operations in another order, and only
+ * the group elements are defined.  num_threads only splits each layer's blocks over threads (test speed). */
+static void g1_fft_in_place(g1j *a, uint32_t k, const fe *omega, int num_threads) {
     size_t n = (size_t)1 << k;
-    if (num_threads < 1) num_threads = 1;
-    fe n_inv, two, omega_inv = FR_ROOT_OF_UNITY_INV;                     /* :278-282 */
-    fe_from_u64(&two, 2, &FR);
-    fe_inv(&two, &two, &FR);
-    { uint64_t e[4] = {k, 0, 0, 0}; fe_pow(&n_inv, &two, e, 4, &FR); }
-    for (uint32_t i = k; i < FR_S; i++) fe_sqr(&omega_inv, &omega_inv, &FR);
-    g1j *a = (g1j *)malloc(n * sizeof(g1j));
-    for (size_t i = 0; i < n; i++) g1j_from_affine(&a[i], &g[i]);        /* g.to_curve() (commitment.rs:274) */
     for (size_t i = 0; i < n; i++) {                                     /* best_fft :186-191 */
         size_t ri = bitreverse(i, k);
         if (i < ri) { g1j t = a[ri]; a[ri] = a[i]; a[i] = t; }
@@ -874,7 +863,7 @@ int oracle_g_to_lagrange(const g1a *g, uint32_t k, g1a *g_lagrange, int num_thre
     size_t nt = n / 2;
     fe *tw = (fe *)malloc((nt ? nt : 1) * sizeof(fe));
     fe w = FR.r;
-    for (size_t i = 0; i < nt; i++) { tw[i] = w; fe_mul(&w, &w, &omega_inv, &FR); }
+    for (size_t i = 0; i < nt; i++) { tw[i] = w; fe_mul(&w, &w, omega, &FR); }   /* :194-200 */
     size_t chunk = 2, twiddle_chunk = n / 2;
     for (uint32_t s = 0; s < k; s++) {
         size_t blocks = n / chunk;
@@ -895,6 +884,32 @@ int oracle_g_to_lagrange(const g1a *g, uint32_t k, g1a *g_lagrange, int num_thre
         chunk *= 2;
         twiddle_chunk /= 2;
     }
+    free(tw);
+}
+
+/* pub fn best_fft<G: Group>(a: &mut [G], omega: G::Scalar, log_n: u32) for G = bn256::G1, on 2^log_n Jacobian points in place */
+int oracle_best_fft_g1(g1j *a, const fe *omega, uint32_t log_n, int num_threads) {
+    oracle_init();
+    if (log_n > FR_S) return -1;
+    if (num_threads < 1) num_threads = 1;
+    g1_fft_in_place(a, log_n, omega, num_threads);
+    return 0;
+}
+
+/* g_to_lagrange (arithmetic.rs:277-301): inverse FFT of the coefficient-basis SRS points, scaled by 1/n, normalised. */
+int oracle_g_to_lagrange(const g1a *g, uint32_t k, g1a *g_lagrange, int num_threads) {
+    oracle_init();
+    if (k > FR_S) return -1;
+    size_t n = (size_t)1 << k;
+    if (num_threads < 1) num_threads = 1;
+    fe n_inv, two, omega_inv = FR_ROOT_OF_UNITY_INV;                     /* :278-282 */
+    fe_from_u64(&two, 2, &FR);
+    fe_inv(&two, &two, &FR);
+    { uint64_t e[4] = {k, 0, 0, 0}; fe_pow(&n_inv, &two, e, 4, &FR); }
+    for (uint32_t i = k; i < FR_S; i++) fe_sqr(&omega_inv, &omega_inv, &FR);
+    g1j *a = (g1j *)malloc(n * sizeof(g1j));
+    for (size_t i = 0; i < n; i++) g1j_from_affine(&a[i], &g[i]);        /* g.to_curve() (commitment.rs:274) */
+    g1_fft_in_place(a, k, &omega_inv, num_threads);                      /* :285 */
     uint64_t e[4];
     fe_to_canonical(e, &n_inv, &FR);
     for (size_t i = 0; i < n; i++) {                                     /* :286-290 then batch_normalize :292-298 */
@@ -902,7 +917,6 @@ int oracle_g_to_lagrange(const g1a *g, uint32_t k, g1a *g_lagrange, int num_thre
         g1j_mul_canonical(&t, &a[i], e);
         g1j_to_affine(&g_lagrange[i], &t);
     }
-    free(tw);
     free(a);
     return 0;
 }

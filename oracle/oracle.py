@@ -223,6 +223,16 @@ def kzg_setup(k, secret_mont):
     return g, gl
 
 
+def best_fft_g1(a_xyz, omega, log_n, num_threads=1):
+    """arithmetic.rs:171-234 with G = bn256::G1: (n, 12) Jacobian points -> (n, 12) Jacobian points (a copy is transformed)"""
+    a = _c(a_xyz).copy()
+    assert a.shape == (1 << log_n, 12)
+    rc = lib().oracle_best_fft_g1(_p(a), _p(_c(omega)), ctypes.c_uint32(log_n), int(num_threads))
+    if rc != 0:
+        raise ValueError("oracle_best_fft_g1 rc=%d" % rc)
+    return a
+
+
 def g_to_lagrange(g, k, num_threads=1):
     """arithmetic.rs:277-301: (n, 8) affine coefficient-basis points -> (n, 8) affine Lagrange-basis points"""
     g = _c(g)

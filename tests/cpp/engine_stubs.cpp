@@ -20,6 +20,7 @@ void msm_set_split_records(bool) {}
 void msm_set_bucket_order(int) {}
 void msm_set_quad_tail(bool) {}
 void msm_set_split_buckets(bool) {}
+void msm_set_plane_tail(bool) {}
 void ecfft_set_quad(bool) {}
 void msm_set_fuse_limits(size_t, size_t) {}
 void msm_set_rowcol(uint64_t, uint32_t) {}
@@ -48,6 +49,7 @@ void evalh_rtc_shutdown() {}
 int evaluate_h_validate(const h2hip_evalh_desc*, const void*) { return 0; }
 int evaluate_h_host(Ctx*, const h2hip_evalh_desc*, uint64_t*, bool, hipStream_t) { return 0; }
 int g_to_lagrange_device(Ctx*, const Affine*, uint32_t, Affine*, hipStream_t) { return 0; }
+int fft_g1_device(Ctx*, Jac*, const Fe&, uint32_t, hipStream_t) { return 0; }
 int kzg_setup_device(Ctx*, uint32_t, const Fe&, Affine*, Affine*, hipStream_t) { return 0; }
 int scale_periodic_device(Ctx*, Fe*, uint64_t, const uint64_t*, uint32_t, hipStream_t) { return 0; }
 

@@ -393,7 +393,6 @@ def test_oracle_evaluate_h_degenerate_systems(oracle, variant):
     elif variant == "empty_graph":
         case = _strip(case, perm=False, lookups=False)
         case["custom"] = flatten_graph(GraphEvaluator())
-        gates_kernel["expect_generated"] = False  # no operations: nothing to generate, the interpreter's empty loop stores the zero
         want = np.zeros_like(vin)
     else:
         case = _strip(case, perm=variant not in ("no_perm", "gates_only"), lookups=variant not in ("no_lookups", "gates_only"))
@@ -520,7 +519,8 @@ def test_generated_gates_kernel_compiles_for_gfx950(h2, oracle, evalh_golden):
     src, secs, size = _codegen(h2, case["custom"])
     n_ops, n_slots = _compile_stats(h2, case["custom"])
     assert 'extern "C" __global__ void' in src and "evalh_gates_gen" in src and size > 1000
-    assert sum(1 for ln in src.splitlines() if ln.startswith("    s") and " = " in ln) >= n_ops
+    # one statement per operation, except the products emitted inside the sum that consumes them (two per fused ADD / SUB, one per Horner step)
+    assert sum(1 for ln in src.splitlines() if ln.startswith("    s") and " = " in ln) >= n_ops - 2 * src.count("fu_mul_sub<UF>")
     big, _ = _random_case(oracle, 5, seed=5, n_gates=40)
     src, secs, size = _codegen(h2, big["custom"])
     assert size > 1000 and secs < 120

@@ -129,3 +129,58 @@ def test_kzg_setup_vs_oracle_and_contract(h2, oracle):
         h2.ParamsKZG.setup(4, 1)
     with pytest.raises(h2.H2HipError):
         h2.ParamsKZG.setup(29, 5)
+
+
+# ---------------------------------------------------------------------------- best_fft::<G1> with a caller-supplied omega
+def _jac(affine):
+    """(n, 8) affine points -> (n, 12) Jacobian with z = one (Montgomery form), identity (0, 0) -> z = 0"""
+    from oracle import oracle as orc
+    one = orc.fe_from_int(orc.FQ, 1)
+    out = np.zeros((affine.shape[0], 12), dtype=np.uint64)
+    out[:, :8] = affine
+    ident = ~affine.any(axis=1)
+    out[~ident, 8:] = one
+    out[ident, 4:8] = one
+    return out
+
+
+def _aff_all(orc, jac):
+    return np.stack([orc.g1_to_affine(p) for p in jac])
+
+
+@pytest.mark.parametrize("k", [0, 1, 3, 5])
+def test_oracle_best_fft_g1_is_the_scalar_ntt_in_the_exponent(oracle, k):
+    """an independent pin of the curve-point FFT: for P_i = [a_i]G, best_fft::<G1>(P, omega) = [best_fft::<Fr>(a, omega)_j]G -- the
+    oracle's G1 butterflies against its Fr transform (itself pinned by the O(n^2) golden DFTs) and plain scalar multiplication"""
+    d, _ = oracle.domain_new(2, max(k, 1))
+    omega = d.fe("omega") if k else oracle.fe_from_int(oracle.FR, 1)
+    n = 1 << k
+    a = oracle.gen_scalars(31 + k, n)
+    gen = np.zeros(8, dtype=np.uint64)
+    gen[:4], gen[4:] = oracle.fe_from_int(oracle.FQ, 1), oracle.fe_from_int(oracle.FQ, 2)
+    pts = np.stack([oracle.g1_to_affine(oracle.g1_mul(gen, a[i])) for i in range(n)])
+    got = _aff_all(oracle, oracle.best_fft_g1(_jac(pts), omega, k, num_threads=2))
+    fa = oracle.best_fft(a, omega, k, 1) if k else a
+    want = np.stack([oracle.g1_to_affine(oracle.g1_mul(gen, fa[i])) for i in range(n)])
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [0, 1, 4, 8, 11, 15])
+def test_gpu_best_fft_g1_vs_oracle(h2, oracle, k):
+    """arithmetic.rs:171-234 with G = bn256::G1 and the caller's omega (forward root here; g_to_lagrange passes the inverse one):
+    the same group elements as the oracle's iterative butterflies, identities and non-trivial z among the inputs"""
+    h2.init()
+    d, _ = oracle.domain_new(2, max(k, 1))
+    omega = d.fe("omega") if k else oracle.fe_from_int(oracle.FR, 1)
+    n = 1 << k
+    pts = oracle.gen_points(700 + k, n, num_threads=8)
+    a = _jac(pts)
+    if n >= 8:
+        a[3] = _jac(np.zeros((1, 8), dtype=np.uint64))[0]     # an identity
+        a[5] = oracle.best_multiexp(oracle.gen_scalars(9, 4), pts[:4], 1)  # a point with z != 1
+    want = _aff_all(oracle, oracle.best_fft_g1(a, omega, k, num_threads=16))
+    got = a.copy()
+    h2.best_fft_g1(got, omega, k)
+    assert np.array_equal(_aff_all(oracle, got), want)
+    assert all((p[8:] == oracle.fe_from_int(oracle.FQ, 1)).all() or not p[8:].any() for p in got)  # z = 1, or the identity's z = 0
