@@ -58,6 +58,14 @@ def run(h2, cpu=True, fixed_base=True, scalars="dense", idle_s=0.0, prewarm_ms=1
         milliseconds at idle clocks -- `--idle S` reproduces that on purpose."""
         f()
         torch.cuda.synchronize()
+        import gc
+        keep_gc = os.environ.get("H2_TRACE_GC") == "1"
+        if not keep_gc:  # ahead of the warm-up, not between it and the repetitions: the 25-45 ms the pass takes are GPU idle time, and the
+            # first repetitions after such a gap run 5-15 % slow (clocks) -- measured when the pass sat right before them
+            t_gc = time.perf_counter()
+            gc.collect()
+            if name:  # how long ONE full pass takes in this process: the size of the stall a repetition would have carried
+                rep_log.setdefault("full_gc_pass_ms", []).append(round((time.perf_counter() - t_gc) * 1e3, 2))
         if name and idle_s:
             time.sleep(idle_s)
         if name and prewarm_ms:
@@ -71,13 +79,6 @@ def run(h2, cpu=True, fixed_base=True, scalars="dense", idle_s=0.0, prewarm_ms=1
         # inside whichever repetition happens to trigger it.  Round 3's driver line carried one (36 ms "per repetition" = 3 x 7.6 + 85).
         # The collector is therefore run once up front and kept off during the repetitions; the count of full collections per
         # repetition rides along as evidence (0 with the collector off; `H2_TRACE_GC=1` leaves it on to show the effect).
-        import gc
-        keep_gc = os.environ.get("H2_TRACE_GC") == "1"
-        if not keep_gc:
-            t_gc = time.perf_counter()
-            gc.collect()
-            if name:  # how long ONE full pass takes in this process: the size of the stall a repetition would have carried
-                rep_log.setdefault("full_gc_pass_ms", []).append(round((time.perf_counter() - t_gc) * 1e3, 2))
         was_enabled = gc.isenabled()
         if not keep_gc:
             gc.disable()
