@@ -73,6 +73,48 @@ def pmc_traffic(workload):
         return None
 
 
+def measure_traffic(log_n, form, kernel="msm_accum_kernel", timeout=150):
+    """HBM bytes per launch of the dominant kernel, measured by THIS run: two child processes under `rocprofv3 --pmc` (FETCH_SIZE and
+    WRITE_SIZE in separate passes, no trace domain in either, as the MI355X guide's HBM section prescribes), each running nothing but
+    the timed step (`bench.py --only-step`).  Counter units are KiB; the read side takes factor 1 for this kernel (per-lane 64-B gathers:
+    the raw counter already exceeds the known gather volume, see profiles/pmc_traffic.json's note), WRITE_SIZE is exact.  Returns a dict
+    or None when rocprofv3 is missing or a pass fails (the committed figure then stands in, labelled as such)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k_ in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k_, None)
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="h2pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--only-step",
+                   "--log-n", str(log_n), "--form", form, "--steps", "5", "--warmup", "2", "--prewarm-ms", "0"]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd="/tmp")
+            tot, n = 0.0, 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == counter and kernel in row.get("Kernel_Name", ""):
+                            tot += float(row["Counter_Value"])
+                            n += 1
+            if r.returncode != 0 or n == 0:
+                return None
+            out[counter] = (tot / n * 1024.0, n)
+    except (OSError, subprocess.SubprocessError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"hbm_bytes_per_launch": out["FETCH_SIZE"][0] + out["WRITE_SIZE"][0], "read_bytes": out["FETCH_SIZE"][0], "write_bytes": out["WRITE_SIZE"][0],
+            "launches": [out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]], "read_factor": 1.0}
+
+
 def windows_of(c):
     return (255 + c - 1) // c
 
@@ -181,13 +223,14 @@ def main():
     ap.add_argument("--config4-log-n", type=int, default=24, help="N > 1: BASELINE.json configs[3], an MSM of 2^this pairs in TOTAL sharded over the N GPUs "
                     "(strong scaling; 0 = skip)")
     ap.add_argument("--no-inlib", action="store_true", help="N > 1: skip the single-process N-device leg (h2hip_init with N ids)")
+    ap.add_argument("--no-measure-traffic", action="store_true", help="take roofline.traffic from profiles/pmc_traffic.json instead of measuring it with two rocprofv3 --pmc child passes")
     ap.add_argument("--only-step", action="store_true", help="nothing but the timed step (counter passes: one kernel mix per run)")
     ap.add_argument("--only-ntt", action="store_true", help="nothing but the NTT leg (counter passes)")
     ap.add_argument("--inlib", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.only_step or args.only_ntt:
-        args.no_cpu_baseline = args.no_sizes = args.no_next_rows = args.no_inlib = True
+        args.no_cpu_baseline = args.no_sizes = args.no_next_rows = args.no_inlib = args.no_measure_traffic = True
         args.batch = 0
         args.config4_log_n = 0
         args.no_ntt = args.only_step
@@ -715,6 +758,14 @@ def main():
         adds = world * n * W * args.steps
         accum_ms = accum_ms_live or stages.get("msm_accum")
         roof = msm_roofline(n, accum_ms, "msm_2p%d_%s" % (args.log_n, args.form)) if accum_ms else None
+        if roof and solo and not args.no_measure_traffic:  # the dominant kernel's HBM bytes, re-observed by this run
+            live = measure_traffic(args.log_n, args.form)
+            if live:
+                roof["traffic_committed"] = roof["traffic"]
+                roof["traffic"] = live["hbm_bytes_per_launch"]
+                roof["traffic_read_write_bytes"] = [live["read_bytes"], live["write_bytes"]]
+                roof["traffic_source"] = ("measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE as two separate child passes of `bench.py --only-step` "
+                                          "(%d / %d launches of msm_accum_kernel averaged; KiB counters, read factor 1 for 64-B gathers: profiles/pmc_traffic.json's note)" % tuple(live["launches"]))
         # second roofline, the one that actually binds: 256-bit modular multiplies per second against the
         # multiplier's measured chip-wide peak (tools/mul_rate.hip: 179 G/s for the explicit-mad form at >= 4 waves/SIMD)
         valu = None

@@ -1,6 +1,8 @@
 """Randomised cross-checks on the GPU box (not part of the test suite; run by hand):
   * MSM: random sizes (not powers of two) and scalar shapes, plain form, fixed-base form and the CPU oracle agree in affine;
-  * NTT: every size 2^1..2^22, both plans and both twiddle sources agree limb for limb, round trips restore the input."""
+  * NTT: every size 2^1..2^22, both plans and both twiddle sources agree limb for limb, round trips restore the input;
+  * round 4: random window widths through both reduction tails (host-finished and all-GPU), host-pointer batched transforms with random
+    column counts / run cuts / step grouping against the device-resident transform, lone and batched calls on one domain interleaved."""
 import ctypes, os, random, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -97,5 +99,64 @@ for it in range(int(os.environ.get("COSET_CASES", "24"))):
     ok = all(torch.equal(g_, w) and torch.equal(g2, w) for g_, g2, w in zip(got, got2, want))
     bad += not ok
     print("coset 2^%d -> 2^%d x %d %s" % (k, ek, cnt, "ok" if ok else "MISMATCH"), flush=True)
+# round 4 (a): window widths x reduction tails.  The host-finished tail (bit planes + Horner on the host) and the all-GPU tail must give the
+# oracle's group element for every width the table builder accepts, on uniform, mostly-zero and all-equal columns.
+for it in range(int(os.environ.get("TAIL_CASES", "16"))):
+    n = rng.choice([257, 4096, 20000, rng.randrange(2, 100000)])
+    c = rng.choice([5, 8, 11, 13, 14, 16, 17, 19, 20, 22])
+    bs = oracle.gen_points(7000 + it, n, num_threads=NT)
+    sc = oracle.gen_scalars(7100 + it, n, num_threads=NT)
+    kind = rng.randrange(3)
+    if kind == 1:
+        sc[np.array([rng.random() < 0.95 for _ in range(n)])] = 0
+    elif kind == 2:
+        sc[:] = sc[0]
+    want = oracle.g1_to_affine(oracle.best_multiexp(sc, bs, NT))
+    h2.set_msm_window(c)
+    h2.bases_pin(bs)
+    try:
+        got = []
+        for on in (1, 0):
+            L.h2hip_debug_set_msm_plane_tail(ctypes.c_int(on))
+            got.append(h2.g1_to_affine(h2.best_multiexp(sc, bs)))
+    finally:
+        L.h2hip_debug_set_msm_plane_tail(ctypes.c_int(1))
+        h2.bases_unpin(bs)
+        h2.set_msm_window(0)
+    ok = np.array_equal(got[0], want) and np.array_equal(got[1], want)
+    bad += not ok
+    print("tail n=%d c=%d kind=%d %s" % (n, c, kind, "ok" if ok else "MISMATCH"), flush=True)
+# round 4 (b): host-pointer batched transforms (three-stage pipeline, copier threads) against the device-resident transform of the same
+# columns; random run cuts and step grouping; a lone call on the same domain in between (the plans' twiddle tables coexist)
+for it in range(int(os.environ.get("HOSTBATCH_CASES", "16"))):
+    k = rng.randrange(1, 19)
+    cnt = rng.randrange(1, 12)
+    d = h2.EvaluationDomain.new(4, k)
+    ek = d.extended_k
+    cols_d = [h2.gen_scalars_device(9000 + 16 * it + j, 1 << k) for j in range(cnt)]
+    cols_h = [h2.to_numpy_u64(c_).copy() for c_ in cols_d]
+    col_bytes = 32 << ek
+    L.h2hip_debug_set_ntt_host_batch(ctypes.c_uint64(rng.choice([0, 0, 2 * col_bytes, 3 * col_bytes + 7, 1])), ctypes.c_uint64(rng.choice([0, 1, 4 * col_bytes, 64 << 20])))
+    want_i = []
+    for c_ in cols_d:
+        x = c_.clone()
+        h2.ifft_device(x, d.omega_inv, k, d.ifft_divisor)
+        want_i.append(x)
+    lone = d.lagrange_to_coeff(cols_h[0])
+    got_i = d.lagrange_to_coeff_batch(cols_h)
+    got_e = d.coeff_to_extended_batch(got_i)
+    want_e = []
+    for x in want_i:
+        e = torch.zeros((1 << ek, 4), dtype=torch.int64, device="cuda")
+        e[:1 << k] = x.view(-1, 4)
+        h2.coeff_to_extended_device(e, k, ek, d.extended_omega, d.g_coset, d.g_coset_inv)
+        want_e.append(e)
+    torch.cuda.synchronize()
+    ok = np.array_equal(lone, h2.to_numpy_u64(want_i[0]))
+    ok = ok and all(np.array_equal(g_, h2.to_numpy_u64(w)) for g_, w in zip(got_i, want_i))
+    ok = ok and all(np.array_equal(g_, h2.to_numpy_u64(w)) for g_, w in zip(got_e, want_e))
+    L.h2hip_debug_set_ntt_host_batch(ctypes.c_uint64(0), ctypes.c_uint64(0))
+    bad += not ok
+    print("host batch 2^%d x %d %s" % (k, cnt, "ok" if ok else "MISMATCH"), flush=True)
 print("FAILURES", bad)
 sys.exit(1 if bad else 0)
