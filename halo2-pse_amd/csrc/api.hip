@@ -40,6 +40,7 @@ void msm_set_quad_tail(bool on);
 void msm_set_split_buckets(bool on);
 void msm_set_plane_tail(bool on);
 void ecfft_set_quad(bool on);
+void ecfft_set_lazy(bool on);
 void msm_set_fuse_limits(size_t entries, size_t max_n);
 void msm_set_rowcol(uint64_t lanes, uint32_t flavour);
 void ntt_set_smax(uint32_t v);

@@ -181,6 +181,86 @@ __global__ void __launch_bounds__(256) ecfft_layer_quad_kernel(EcfftLayer L) {
     L.out[ib] = lo;
 }
 
+// Small transforms (k <= 14; round 4): the points stay XYZZ between the layers.  A layer of <= 2^13 butterflies is a latency chain on a
+// fraction of the chip, and the batched normalisation that followed every layer -- one Fermat inversion per lane, ~380 dependent
+// multiplications = 0.17 ms, plus a launch -- was a fifth of the call at k = 12 for the sake of mixed additions in a table of 15 entries.
+// Here the ladder's base point is XYZZ: phi(p) = (BETA * X, Y, ZZ, ZZZ), the table is built with general additions (13 x 4.8
+// multiplications more than with mixed ones, of ~4 000 per ladder), the butterflies run in place (each owns its two elements) and only the
+// final layer's result is normalised.
+__device__ XYZZu ec_mul_xyzz_glv_q(const XYZZu& p, const GlvScalar& k, uint32_t role) {
+    if (xyzzu_is_identity(p)) return xyzzu_identity();
+    const uint32_t BETA_I[9] = {0x0a337995u, 0x158d1d23u, 0x189c9b98u, 0x12fa4e45u, 0x185faadcu, 0x0176f16du, 0x0eed93bau, 0x14291140u, 0x000c0afeu};
+    XYZZu p1 = p, p2 = p;
+    p2.x = fu_mul<QU>(p.x, fu_const<QU>(BETA_I));
+    if (k.neg1) p1.y = fu_norm(fu_neg(p1.y));
+    if (k.neg2) p2.y = fu_norm(fu_neg(p2.y));
+    XYZZu tab[16];  // tab[a + 4 b] = a * p1 + b * p2
+    tab[0] = xyzzu_identity();
+    tab[1] = p1;
+    tab[2] = xyzzu_double_q(p1, role);
+    tab[3] = xyzzu_sum_q(tab[2], p1, role);
+    tab[4] = p2;
+    tab[8] = xyzzu_double_q(p2, role);
+    tab[12] = xyzzu_sum_q(tab[8], p2, role);
+    for (int b = 1; b < 4; b++)
+        for (int a = 1; a < 4; a++) tab[a + 4 * b] = xyzzu_sum_q(tab[a + 4 * (b - 1)], p2, role);
+    XYZZu acc = xyzzu_identity();
+    for (int i = 64; i >= 0; i--) {
+        acc = xyzzu_double_q(xyzzu_double_q(acc, role), role);
+        const uint32_t d1 = (k.k1[i >> 4] >> ((i & 15) * 2)) & 3, d2 = (k.k2[i >> 4] >> ((i & 15) * 2)) & 3;
+        const uint32_t d = d1 | (d2 << 2);
+        if (d) xyzzu_add_q(acc, tab[d], role);
+    }
+    return acc;
+}
+
+struct EcfftLayerX {
+    const Affine* in;     // layer 0 reads the affine input (bit-reversed); later layers read buf
+    XYZZ* buf;            // the points of the transform, in place
+    const GlvScalar* tw;
+    uint32_t log_n, s;
+};
+
+__global__ void __launch_bounds__(256) ecfft_layer_quad_x_kernel(EcfftLayerX L) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t tid = gid >> 2;
+    const uint32_t role = (uint32_t)gid & 3;
+    const uint64_t n = 1ull << L.log_n;
+    if (tid >= n / 2) return;
+    const uint64_t half = 1ull << L.s;
+    const uint64_t i = tid & (half - 1), blk = tid >> L.s;
+    const uint64_t ia = (blk << (L.s + 1)) + i, ib = ia + half;
+    XYZZ a, b;
+    if (L.s == 0) {  // best_fft's swap loop (arithmetic.rs:186-191), folded into the first layer's loads
+        a = xyzz_from_affine(L.in[__brevll(ia) >> (64 - L.log_n)]);
+        b = xyzz_from_affine(L.in[__brevll(ib) >> (64 - L.log_n)]);
+    } else {
+        a = L.buf[ia];
+        b = L.buf[ib];
+    }
+    XYZZ t = b;  // twiddle one
+    if (i != 0) t = xyzzu_to_ext(ec_mul_xyzz_glv_q(xyzzu_from_ext(b), L.tw[i << (L.log_n - 1 - L.s)], role));
+    if (role != 0) return;  // the two closing additions are canonical arithmetic: one lane
+    XYZZ hi = a, lo = a;
+    xyzz_add(hi, t);  // a + t
+    t.y = fe_neg<FqP>(t.y);
+    xyzz_add(lo, t);  // a - t
+    L.buf[ia] = hi;
+    L.buf[ib] = lo;
+}
+
+// [e] p for XYZZ points (the final 1 / n of g_to_lagrange on the un-normalised path): the scalar is the same for every point, so it is
+// decomposed once on the host and every point takes the quad GLV ladder of the butterflies -- 130 quad doublings + 65 quad additions
+// (~0.5 ms of latency) where plain double-and-add on one lane per point walked 254 doublings + ~127 additions (~2 ms, a third of the call at k = 8)
+__global__ void __launch_bounds__(256) ec_scale_xyzz_quad_kernel(XYZZ* buf, uint64_t n, GlvScalar e) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t tid = gid >> 2;
+    const uint32_t role = (uint32_t)gid & 3;
+    if (tid >= n) return;
+    const XYZZ r = xyzzu_to_ext(ec_mul_xyzz_glv_q(xyzzu_from_ext(buf[tid]), e, role));
+    if (role == 0) buf[tid] = r;
+}
+
 __global__ void __launch_bounds__(256) ec_scale_kernel(const Affine* in, XYZZ* out, uint64_t n, Scalar256 e) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= n) return;
@@ -233,8 +313,9 @@ __global__ void __launch_bounds__(256) ecfft_twiddle_kernel(GlvScalar* tw, uint6
     tw[tid] = glv_decompose(c.l);
 }
 
-static bool g_ecfft_quad = true;
+static bool g_ecfft_quad = true, g_ecfft_lazy = true;
 void ecfft_set_quad(bool on) { g_ecfft_quad = on; }
+void ecfft_set_lazy(bool on) { g_ecfft_lazy = on; }  // k <= 14: no normalisation between the layers (round 4); off: round 3's path
 
 static int normalize_launch(const XYZZ* in, Affine* out, uint64_t n, hipStream_t s) {
     const uint64_t lanes = (n + EC_NORM_CHUNK - 1) / EC_NORM_CHUNK;
@@ -294,6 +375,23 @@ static int ecfft_device(Ctx* c, const Affine* d_in, uint32_t k, Affine* d_out, c
         H2_CHECK(hipGetLastError());
     }
     const Affine* src = d_in;
+    if (g_ecfft_quad && g_ecfft_lazy && k >= 1 && k <= 14) {
+        // small transforms: the points stay XYZZ across the layers (in place), one normalisation at the very end
+        for (uint32_t layer = 0; layer < k; layer++) {
+            EcfftLayerX L = {d_in, d_xyzz, d_tw, k, layer};
+            hipLaunchKernelGGL(ecfft_layer_quad_x_kernel, dim3((uint32_t)((2 * n + 255) / 256)), dim3(256), 0, s, L);
+            H2_CHECK(hipGetLastError());
+        }
+        if (scale) {
+            const Fe sc = fe_to_canonical<FrP>(*scale);
+            const GlvScalar e = glv_decompose(sc.l);
+            hipLaunchKernelGGL(ec_scale_xyzz_quad_kernel, dim3((uint32_t)((4 * n + 255) / 256)), dim3(256), 0, s, d_xyzz, n, e);
+            H2_CHECK(hipGetLastError());
+        }
+        if ((rc = normalize_launch(d_xyzz, d_out, n, s))) return rc;
+        c->timer_end(tid, s);
+        return guard.release();
+    }
     for (uint32_t layer = 0; layer < k; layer++) {
         EcfftLayer L = {src, d_xyzz, d_tw, k, layer};
         if (g_ecfft_quad && k <= 14)  // few butterflies per layer (<= 2^13: fewer lanes than SIMD slots even four to a butterfly)

@@ -25,7 +25,8 @@ int h2hip_debug_set_msm_max_chunk(size_t m);
 int h2hip_debug_rccl_gather_selftest(const uint64_t* partials_xyz, size_t count, uint64_t* out_xyz);
 /* buckets with more than (entries of the MSM) / d entries take the chunked path (default d = 32768; 0 restores it) */
 int h2hip_debug_set_msm_heavy_div(size_t d);
-/* g_to_lagrange up to k = 14: one quad of lanes per butterfly (1, default) or one lane (0) */
+/* g_to_lagrange / fft_g1 up to k = 14: bit 0 -- one quad of lanes per butterfly (1, default) or one lane (0); bit 1 set -- normalise to affine
+ * after every layer as round 3 did (default clear: the points stay XYZZ between the layers, one normalisation at the end) */
 int h2hip_debug_set_g2l_quad(int on);
 /* fused batches: at most `entries` entries per fused run (0 = 2^26), MSMs of at most `max_n` pairs are fused (0 = 2^19) */
 int h2hip_debug_set_msm_fuse_limits(size_t entries, size_t max_n);

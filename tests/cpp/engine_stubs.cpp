@@ -22,6 +22,7 @@ void msm_set_quad_tail(bool) {}
 void msm_set_split_buckets(bool) {}
 void msm_set_plane_tail(bool) {}
 void ecfft_set_quad(bool) {}
+void ecfft_set_lazy(bool) {}
 void msm_set_fuse_limits(size_t, size_t) {}
 void msm_set_rowcol(uint64_t, uint32_t) {}
 void ntt_set_smax(uint32_t) {}

@@ -184,3 +184,25 @@ def test_gpu_best_fft_g1_vs_oracle(h2, oracle, k):
     h2.best_fft_g1(got, omega, k)
     assert np.array_equal(_aff_all(oracle, got), want)
     assert all((p[8:] == oracle.fe_from_int(oracle.FQ, 1)).all() or not p[8:].any() for p in got)  # z = 1, or the identity's z = 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2, 5, 9, 13, 14])
+def test_gpu_small_transforms_lazy_and_normalised_paths_agree(h2, oracle, k):
+    """k <= 14: the layers keep their points XYZZ and normalise once at the end (round 4) -- same affine output as round 3's path (a
+    normalisation after every layer), as the one-lane ladder, and as the oracle; identities and repeated points among the inputs"""
+    import ctypes
+    h2.init()
+    L = h2.lib()
+    n = 1 << k
+    g = oracle.gen_points(1300 + k, n, num_threads=8)
+    if n >= 8:
+        g[2] = 0
+        g[6] = g[1]
+    want = oracle.g_to_lagrange(g, k, num_threads=16)
+    try:
+        for mode in (1, 3, 0):  # lazy quad (default), normalised quad, one lane per butterfly
+            L.h2hip_debug_set_g2l_quad(ctypes.c_int(mode))
+            assert np.array_equal(h2.g_to_lagrange(g, k), want), mode
+    finally:
+        L.h2hip_debug_set_g2l_quad(ctypes.c_int(1))
