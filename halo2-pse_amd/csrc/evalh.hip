@@ -757,13 +757,22 @@ static std::string gen_source(const h2hip_graph& g, const Program& P) {
     return src;
 }
 
-static uint64_t fnv1a64(const std::string& s) {
-    uint64_t h = 0xcbf29ce484222325ull;
-    for (unsigned char ch : s) {
-        h ^= ch;
+static uint64_t fnv1a64_raw(const char* p, size_t n, uint64_t h) {
+    for (size_t i = 0; i < n; i++) {
+        h ^= (unsigned char)p[i];
         h *= 0x100000001b3ull;
     }
     return h;
+}
+// key of a generated kernel: its source AND the embedded headers it is compiled against (a code object left in HALO2_HIP_CACHE_DIR by
+// another build of the library, whose arithmetic headers differ, must not be picked up)
+static uint64_t fnv1a64(const std::string& s) {
+    static const uint64_t headers = [] {
+        uint64_t h = 0xcbf29ce484222325ull;
+        for (int i = 0; i < H2_RTC_N_HEADERS; i++) h = fnv1a64_raw(H2_RTC_HEADER_TEXT[i], strlen(H2_RTC_HEADER_TEXT[i]), h);
+        return h;
+    }();
+    return fnv1a64_raw(s.data(), s.size(), headers);
 }
 
 struct RtcEntry {
@@ -773,6 +782,10 @@ struct RtcEntry {
     std::string log;
     std::thread th;
     double compile_s = 0.0;
+    // a process that exits without h2hip_shutdown still destroys the cache (static destruction): a joinable std::thread must not meet its destructor
+    ~RtcEntry() {
+        if (th.joinable()) th.join();
+    }
 };
 static std::map<uint64_t, std::shared_ptr<RtcEntry>> g_rtc;
 

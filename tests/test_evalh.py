@@ -560,3 +560,49 @@ def test_gpu_evaluate_h_random_graphs(h2, oracle, gates_kernel):
         got = vin.copy()
         assert h2.lib().h2hip_evaluate_h_bn254(h.byref(), got.ctypes.data_as(ctypes.c_void_p)) == 0, h2.lib().h2hip_last_error()
         assert np.array_equal(got, want), "graph %d" % i
+
+
+_DISK_CACHE = r"""
+import ctypes, json, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from conftest import load_pkg
+from oracle import oracle
+import test_evalh as T
+h2 = load_pkg()
+h2.init()
+L = h2.lib()
+L.h2hip_debug_set_evalh_codegen(ctypes.c_int(2), ctypes.c_uint32(0))
+case, vin = T._random_case(oracle, 6, seed=77)
+h = T.DescHolder(case)
+want = vin.copy()
+assert oracle.lib().oracle_evaluate_h(h.byref(), want.ctypes.data_as(ctypes.c_void_p)) == 0
+got = vin.copy()
+assert L.h2hip_evaluate_h_bn254(h.byref(), got.ctypes.data_as(ctypes.c_void_p)) == 0, L.h2hip_last_error()
+st = (ctypes.c_uint64 * 5)()
+L.h2hip_debug_evalh_codegen_stats(st)
+print("RESULT " + json.dumps({"match": bool(np.array_equal(got, want)), "compiled": st[0], "failed": st[1], "launches": st[2], "disk_hits": st[4],
+                              "files": sorted(os.listdir(os.environ["HALO2_HIP_CACHE_DIR"]))}))
+"""
+
+
+@pytest.mark.gpu
+def test_generated_kernel_disk_cache_across_processes(tmp_path):
+    """HALO2_HIP_CACHE_DIR: the first process compiles the circuit's gates kernel and leaves the code object behind, a second process
+    finds it (no hiprtc compile: `disk_hits`), and both match the oracle"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HALO2_HIP_CACHE_DIR=str(tmp_path))
+    outs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-c", _DISK_CACHE % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:]))
+    first, second = outs
+    assert first["match"] and second["match"]
+    assert first["disk_hits"] == 0 and first["compiled"] == 1 and first["launches"] >= 1 and len(first["files"]) == 1 and first["files"][0].endswith("_gfx950.co")
+    assert second["disk_hits"] == 1 and second["launches"] >= 1 and second["files"] == first["files"]
