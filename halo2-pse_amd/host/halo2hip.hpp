@@ -106,6 +106,13 @@ inline void best_fft(std::vector<Fr>& a, const Fr& omega, uint32_t log_n) {
     engine_check(h2hip_ntt_bn254_fr(a[0].l, omega.l, log_n), "best_fft");
 }
 
+// best_fft with G = G1 (arithmetic.rs:171-234; in the crate: g_to_lagrange, :285): in place on Jacobian points, the caller's omega.
+// Only the group elements are defined by the reference; they come back with z = 1 (identity: z = 0).
+inline void best_fft(std::vector<G1>& a, const Fr& omega, uint32_t log_n) {
+    if (log_n > 63 || a.size() != (size_t(1) << log_n)) throw std::logic_error("assertion failed: n == 1 << log_n");  // :184
+    engine_check(h2hip_fft_bn254_g1(a[0].x, omega.l, log_n), "best_fft::<G1>");
+}
+
 // g_to_lagrange (arithmetic.rs:277-301); takes the affine points (the reference converts them with to_curve() at the call site)
 inline std::vector<G1Affine> g_to_lagrange(const std::vector<G1Affine>& g, uint32_t k) {
     if (g.size() != (size_t(1) << k)) throw std::logic_error("assertion failed: a.len() == 1 << log_n");  // best_fft, :184
@@ -180,6 +187,36 @@ class EvaluationDomain {
         if (a.values.size() != (size_t(1) << k)) throw std::logic_error("assertion failed: a.values.len() == 1 << self.k");  // :227
         engine_check(h2hip_ifft_bn254_fr(a.values[0].l, omega_inv.l, k, ifft_divisor.l), "lagrange_to_coeff");            // :230
         return {std::move(a.values)};
+    }
+
+    // the same for the columns create_proof converts back to back (plonk/prover.rs:476-490; patch 0004's lagrange_to_coeff_batch): one
+    // pipelined engine call -- column i + 1 goes up and column i - 1 comes down while column i is transformed
+    std::vector<Polynomial<Coeff>> lagrange_to_coeff_batch(std::vector<Polynomial<LagrangeCoeff>> polys) const {
+        std::vector<uint64_t*> cols;
+        for (auto& a : polys) {
+            if (a.values.size() != (size_t(1) << k)) throw std::logic_error("assertion failed: a.values.len() == 1 << self.k");
+            cols.push_back(a.values[0].l);
+        }
+        engine_check(h2hip_ifft_bn254_fr_batch(cols.data(), cols.size(), omega_inv.l, k, ifft_divisor.l), "lagrange_to_coeff_batch");
+        std::vector<Polynomial<Coeff>> out;
+        for (auto& a : polys) out.push_back({std::move(a.values)});
+        return out;
+    }
+
+    // coeff_to_extended for several polynomials (plonk/evaluation.rs:306-323; patch 0004's coeff_to_extended_batch)
+    std::vector<Polynomial<ExtendedLagrangeCoeff>> coeff_to_extended_batch(const std::vector<Polynomial<Coeff>>& polys) const {
+        std::vector<Polynomial<ExtendedLagrangeCoeff>> out(polys.size());
+        std::vector<const uint64_t*> ins;
+        std::vector<uint64_t*> outs;
+        for (size_t i = 0; i < polys.size(); i++) {
+            if (polys[i].values.size() != (size_t(1) << k)) throw std::logic_error("assertion failed: a.values.len() == 1 << self.k");
+            out[i].values.resize(extended_len());
+            ins.push_back(polys[i].values[0].l);
+            outs.push_back(out[i].values[0].l);
+        }
+        engine_check(h2hip_coeff_to_extended_bn254_fr_batch(ins.data(), k, outs.data(), ins.size(), extended_k, extended_omega.l, g_coset.l, g_coset_inv.l),
+                     "coeff_to_extended_batch");
+        return out;
     }
 
     // coeff_to_extended (poly/domain.rs:240-254)

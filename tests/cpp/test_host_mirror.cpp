@@ -101,6 +101,14 @@ static void test_domain_roundtrips() {
     bool same = true;
     for (size_t i = 0; i < back2.size(); i++) same = same && back2[i] == (i < coeffs.len() ? coeffs[i] : Fr::zero());
     CHECK(same);
+    // the batched forms (patch 0004) give, column by column, what the one-column methods give
+    std::vector<Polynomial<LagrangeCoeff>> cols(5, a);
+    for (size_t j = 0; j < cols.size(); j++) cols[j][j] = cols[j][j] + Fr::from(j + 1);
+    auto batch = domain.lagrange_to_coeff_batch(cols);
+    CHECK(batch.size() == cols.size());
+    for (size_t j = 0; j < cols.size(); j++) CHECK(batch[j].values == domain.lagrange_to_coeff(cols[j]).values);
+    auto ext_batch = domain.coeff_to_extended_batch(batch);
+    for (size_t j = 0; j < cols.size(); j++) CHECK(ext_batch[j].values == domain.coeff_to_extended(batch[j]).values);
 }
 
 // the reference panics on these (arithmetic.rs:133,184; poly/domain.rs:227; kzg/commitment.rs:290)
