@@ -73,7 +73,7 @@ def pmc_traffic(workload):
         return None
 
 
-def measure_traffic(log_n, form, kernel="msm_accum_kernel", timeout=150):
+def measure_traffic(log_n, form, kernel="msm_accum_kernel", timeout=100):
     """HBM bytes per launch of the dominant kernel, measured by THIS run: two child processes under `rocprofv3 --pmc` (FETCH_SIZE and
     WRITE_SIZE in separate passes, no trace domain in either, as the MI355X guide's HBM section prescribes), each running nothing but
     the timed step (`bench.py --only-step`).  Counter units are KiB; the read side takes factor 1 for this kernel (per-lane 64-B gathers:
