@@ -37,7 +37,9 @@
  * HALO2_HIP_NTT_TWIDDLE_MB (default 1024) HBM per device for the full inter-pass twiddle tables of 2^20- and 2^21-point
  * transforms (36 bytes per point and domain; without room the two-level table serves, one multiplication more per point);
  * HALO2_HIP_LAZY_PIN=k (default 0 = off) lets the library pin a host bases array by itself once a
- * host-pointer MSM has seen it k times (see h2hip_bases_pin).
+ * host-pointer MSM has seen it k times (see h2hip_bases_pin); HALO2_HIP_EVALH_CODEGEN=0|1|2 the per-circuit custom-gates kernel of
+ * h2hip_evaluate_h_bn254 (0: byte-code interpreter only; 1, default: generated and compiled by hiprtc on a background thread, the interpreter
+ * serves until the code object is ready; 2: compiled inline) and HALO2_HIP_CACHE_DIR a directory that keeps those code objects across processes.
  */
 #ifndef HALO2HIP_H
 #define HALO2HIP_H
@@ -70,7 +72,9 @@ const char* h2hip_version(void);
 int h2hip_device_count(void);
 /* devices the engine is bound to (0 before init) */
 int h2hip_num_devices(void);
-/* dispatch thresholds for the shim: below them the reference's CPU body is the faster path */
+/* dispatch thresholds for the shim: below them the reference's CPU body is the faster path.  Without a usable GPU they answer
+ * "never" (SIZE_MAX / UINT32_MAX) from a cached failure -- no lock, no HIP call -- so the CPU-fallback path of a prover on a GPU-less host costs nothing;
+ * h2hip_init or h2hip_shutdown makes the library look for a device again. */
 size_t h2hip_msm_min_n(void);
 uint32_t h2hip_ntt_min_log_n(void);
 
