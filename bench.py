@@ -662,6 +662,7 @@ def main():
                            "stage_ms": eh["k18"].get("stage_ms"), "gates_valu_roofline": eh["k18"].get("gates_valu_roofline"),
                            "with_the_interpreter": eh["k18"].get("interpreter"), "first_call_with_inline_compile_s": eh["k18"].get("first_call_with_inline_compile_s"),
                            "parity_vs_cpu_k12_generated": eh["check_k12"].get("match_generated"),
+                           "host_pointer_k16": (eh.get("host_k16") or {}).get("host_pointer"),
                            "parity_vs_cpu_k12": eh["check_k12"]["match"], "cpu_port_s_k12": eh["check_k12"]["oracle_s"],
                            "gpu_ms_k12": eh["check_k12"]["gpu_ms"]},
             "g_to_lagrange": {"k16_ms": gl["k16"]["gpu_ms"], "k16_scalar_muls_per_s": gl["k16"]["scalar_muls_per_s"],

@@ -233,6 +233,30 @@ def bases_unpin_device(d_bases):
     _check(lib().h2hip_bases_unpin(_dptr(d_bases)), "h2hip_bases_unpin")
 
 
+def columns_pin(columns):
+    """keep a proving key's constant columns (pk.fixed_cosets, pk.l0 / l_last / l_active_row, pk.permutation.cosets: (2^extended_k, 4)
+    uint64 each) in HBM across host-pointer evaluate_h calls, keyed by their host addresses (h2hip_columns_pin)"""
+    cols = list(columns)
+    if not cols:
+        return
+    for a in cols:
+        assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"] and a.shape == cols[0].shape and a.shape[1] == 4
+    _check(lib().h2hip_columns_pin(_host_ptrs(cols), ctypes.c_size_t(len(cols)), ctypes.c_size_t(cols[0].shape[0])), "h2hip_columns_pin")
+
+
+def columns_unpin(columns):
+    cols = list(columns)
+    if cols:
+        _check(lib().h2hip_columns_unpin(_host_ptrs(cols), ctypes.c_size_t(len(cols))), "h2hip_columns_unpin")
+
+
+def columns_pinned_info():
+    """(columns, bytes of HBM) the pinned-column cache holds"""
+    n, b = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _check(lib().h2hip_columns_pinned_info(ctypes.byref(n), ctypes.byref(b)), "h2hip_columns_pinned_info")
+    return n.value, b.value
+
+
 def bases_pinned_info(bases):
     """(points, window bits, windows, bytes of HBM) of a pinned host array or device tensor"""
     ptr = _p(bases) if isinstance(bases, np.ndarray) else _dptr(bases)

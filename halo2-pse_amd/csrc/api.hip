@@ -277,6 +277,7 @@ struct Config {
     bool allow_dup = false;                    // HALO2_HIP_ALLOW_DUPLICATE_DEVICES=1: rehearsal on a one-GPU box
     bool roctx = false;                        // HALO2_HIP_ROCTX=1: roctx range around every entry point
     uint32_t lazy_pin_after = 0;               // HALO2_HIP_LAZY_PIN=k: a host bases array seen k times unpinned is pinned by the library
+    size_t column_cache_bytes = (size_t)64 << 30;  // HALO2_HIP_COLUMN_CACHE_GB: HBM the pinned proving-key columns may take (least recently used dropped first)
 };
 static Config g_cfg;
 
@@ -301,6 +302,7 @@ static void read_config() {
     if (env_u64("HALO2_HIP_ALLOW_DUPLICATE_DEVICES", &v)) c.allow_dup = v != 0;
     if (env_u64("HALO2_HIP_ROCTX", &v)) c.roctx = v != 0;
     if (env_u64("HALO2_HIP_LAZY_PIN", &v)) c.lazy_pin_after = (uint32_t)v;
+    if (env_u64("HALO2_HIP_COLUMN_CACHE_GB", &v)) c.column_cache_bytes = (size_t)v << 30;
     if (env_u64("HALO2_HIP_NTT_TWIDDLE_MB", &v)) ntt_set_full_twiddle_budget(v << 20);
     if (env_u64("HALO2_HIP_EVALH_CODEGEN", &v)) evalh_debug_set_codegen((int)v, 0);
     if (env_u64("HALO2_HIP_MSM_WINDOW", &v) && v >= 2 && v <= 24) msm_set_window((uint32_t)v);
@@ -937,6 +939,9 @@ static void release_ctx(Ctx* c) {
         if (kv.second.d_sample) (void)hipFree(kv.second.d_sample);
     }
     c->pinned.clear();
+    for (auto& kv : c->pinned_cols) (void)hipFree(kv.second.d);
+    c->pinned_cols.clear();
+    c->pinned_cols_bytes = 0;
     c->pin_flag.release();
     c->ntt_ws.release();
     c->ntt_io.release();
@@ -1068,6 +1073,28 @@ static int msm_device_keyed(Ctx* c, const Fe* const* d_scalars, const Affine* d_
         c->pinned.erase(it);
     }
     return msm_batch_device(c, d_scalars, false, d_bases, n, count, out, s, nullptr);
+}
+
+// (pinned proving-key columns: see h2hip_columns_pin further down)
+static void column_sample(const uint64_t* h_col, size_t elems, uint8_t* out) {
+    for (uint32_t k = 0; k < H2_COL_SAMPLES; k++) memcpy(out + 32 * k, h_col + 4 * pin_sample_index(elems, k), 32);
+}
+
+const Fe* pinned_column_lookup(Ctx* c, const uint64_t* h_col, size_t elems) {
+    auto it = c->pinned_cols.find(h_col);
+    if (it == c->pinned_cols.end()) return nullptr;
+    PinnedColumn& pc = it->second;
+    uint8_t now[H2_COL_SAMPLES * 32];
+    if (pc.elems == elems) column_sample(h_col, elems, now);
+    if (pc.elems != elems || memcmp(now, pc.sample, sizeof(now)) != 0) {  // another array lives at this address now: forget the copy
+        (void)hipDeviceSynchronize();
+        (void)hipFree(pc.d);
+        c->pinned_cols_bytes -= pc.elems * sizeof(Fe);
+        c->pinned_cols.erase(it);
+        return nullptr;
+    }
+    pc.last_use = ++c->pinned_cols_tick;
+    return (const Fe*)pc.d;
 }
 
 }  // namespace h2
@@ -2054,6 +2081,99 @@ int h2hip_extended_to_coeff_bn254_fr_batch(uint64_t* const* a, size_t count, uin
 int h2hip_debug_set_ntt_host_batch(uint64_t run_bytes, uint64_t group_bytes) {
     g_ntt_host_batch_bytes = run_bytes ? (size_t)run_bytes : (size_t)4 << 30;
     g_ntt_host_group_bytes = group_bytes ? (size_t)group_bytes : (size_t)2 << 20;
+    return 0;
+}
+
+// ---- pinned proving-key columns (round 4) ------------------------------------------------------------------------------------------
+// The host-pointer evaluate_h (patch 0003's path) uploads every column it is given, and most of them never change between proofs:
+// pk.fixed_cosets, pk.l0 / l_last / l_active_row and pk.permutation.cosets are functions of the proving key -- 22 of the 27 full-size
+// columns of the k = 18 bench system, 2.8 GB of 3.5 GB per call.  h2hip_columns_pin keeps such columns in HBM keyed by their host
+// pointer; evaluate_h_host looks every full-size host column up and skips the upload on a hit.  Guarded like the pinned bases: a
+// lookup compares H2_COL_SAMPLES sampled elements of the caller's memory (the first, and a geometric ladder to the last) with what was
+// seen at pin time, so a freed and reused allocation costs an upload, never a stale column.  What the samples cannot see is a caller
+// rewriting a pinned column in place; a ProvingKey never does.
+extern "C" int h2hip_columns_pin(const uint64_t* const* cols, size_t count, size_t elems) {
+    if ((count && !cols) || elems == 0 || elems > ((size_t)1 << 28)) {
+        set_error("columns_pin: bad argument");
+        return H2HIP_EINVAL;
+    }
+    for (size_t i = 0; i < count; i++)
+        if (!cols[i]) {
+            set_error("columns_pin: null column %zu", i);
+            return H2HIP_EINVAL;
+        }
+    Entry en("h2hip_columns_pin");
+    if (en.rc) return en.rc;
+    Ctx* c = en.c;  // evaluate_h runs on the engine's first device
+    const size_t bytes = elems * sizeof(Fe);
+    size_t budget;
+    {
+        std::shared_lock<std::shared_mutex> lk(g_engine_mu);
+        budget = g_cfg.column_cache_bytes;
+    }
+    for (size_t i = 0; i < count; i++) {
+        if (pinned_column_lookup(c, cols[i], elems)) continue;  // already there (and still the same array)
+        while (!c->pinned_cols.empty() && c->pinned_cols_bytes + bytes > budget) {  // least recently used first
+            auto victim = c->pinned_cols.begin();
+            for (auto it = c->pinned_cols.begin(); it != c->pinned_cols.end(); ++it)
+                if (it->second.last_use < victim->second.last_use) victim = it;
+            H2_CHECK(hipDeviceSynchronize());
+            (void)hipFree(victim->second.d);
+            c->pinned_cols_bytes -= victim->second.elems * sizeof(Fe);
+            c->pinned_cols.erase(victim);
+        }
+        if (bytes > budget) continue;  // does not fit at all: the call stays correct, this column is uploaded per call
+        PinnedColumn pc;
+        if (hipMalloc(&pc.d, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("columns_pin: out of device memory after %zu of %zu columns (the rest is uploaded per call)", i, count);
+            return H2HIP_ENOMEM;
+        }
+        hipError_t e = hipMemcpyAsync(pc.d, cols[i], bytes, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(pc.d);
+            set_error("columns_pin: upload failed: %s", hipGetErrorString(e));
+            return H2HIP_EDEVICE;
+        }
+        pc.elems = elems;
+        pc.last_use = ++c->pinned_cols_tick;
+        column_sample(cols[i], elems, pc.sample);
+        c->pinned_cols[cols[i]] = pc;
+        c->pinned_cols_bytes += bytes;
+    }
+    return 0;
+}
+
+extern "C" int h2hip_columns_unpin(const uint64_t* const* cols, size_t count) {
+    if (count && !cols) return H2HIP_EINVAL;
+    {
+        std::shared_lock<std::shared_mutex> lk(g_engine_mu);
+        if (!ctx()->ready) return 0;  // nothing is pinned in an engine that is not running; the call never starts it
+    }
+    Entry en("h2hip_columns_unpin");
+    if (en.rc) return en.rc;
+    Ctx* c = en.c;
+    bool synced = false;
+    for (size_t i = 0; i < count; i++) {
+        auto it = c->pinned_cols.find(cols[i]);
+        if (it == c->pinned_cols.end()) continue;
+        if (!synced) {
+            H2_CHECK(hipDeviceSynchronize());  // a queued evaluate_h may still read the copy
+            synced = true;
+        }
+        (void)hipFree(it->second.d);
+        c->pinned_cols_bytes -= it->second.elems * sizeof(Fe);
+        c->pinned_cols.erase(it);
+    }
+    return 0;
+}
+
+extern "C" int h2hip_columns_pinned_info(size_t* n_columns, size_t* device_bytes) {
+    Entry en("h2hip_columns_pinned_info");
+    if (en.rc) return en.rc;
+    if (n_columns) *n_columns = en.c->pinned_cols.size();
+    if (device_bytes) *device_bytes = en.c->pinned_cols_bytes;
     return 0;
 }
 

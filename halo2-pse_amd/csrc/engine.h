@@ -100,6 +100,16 @@ struct PinnedBases {
 
 struct Ctx;
 
+// A constant column of a proving key (pk.fixed_cosets, pk.l0 / l_last / l_active_row, pk.permutation.cosets) kept in HBM across
+// evaluate_h calls, keyed by the host pointer and guarded by a fingerprint as the pinned bases are (api.hip, h2hip_columns_pin)
+#define H2_COL_SAMPLES 16
+struct PinnedColumn {
+    void* d = nullptr;
+    size_t elems = 0;
+    uint64_t last_use = 0;
+    uint8_t sample[H2_COL_SAMPLES * 32];
+};
+
 struct StageTimer {
     std::string name;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -159,6 +169,9 @@ struct Ctx {
     std::map<TwiddleKey, TwiddleTable> twiddles;
     size_t tw_full_bytes = 0;  // HBM held by the two-pass plan's full inter-pass twiddle tables
     std::map<const void*, PinnedBases> pinned;
+    std::map<const void*, PinnedColumn> pinned_cols;  // h2hip_columns_pin: the host-pointer evaluate_h finds a proving key's constant columns here
+    size_t pinned_cols_bytes = 0;
+    uint64_t pinned_cols_tick = 0;
     // profiling
     bool profiling = false;        // every stage bracketed by a pair of events (each record costs the stream ~10 us)
     bool profiling_kernel = false; // only the dominant kernel, timed through its own dispatch (hipExtLaunchKernelGGL): no gap
@@ -247,6 +260,9 @@ int fft_g1_device(Ctx* c, Jac* d_a, const Fe& omega, uint32_t log_n, hipStream_t
 
 // setup.hip
 int kzg_setup_device(Ctx* c, uint32_t k, const Fe& s, Affine* d_g, Affine* d_gl, hipStream_t stream);
+
+// api.hip: the device copy of a pinned host column whose fingerprint still matches the caller's memory, or nullptr
+const Fe* pinned_column_lookup(Ctx* c, const uint64_t* h_col, size_t elems);
 
 // evalh.hip
 void evalh_debug_set_max_local_slots(uint32_t v);

@@ -1167,18 +1167,20 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         return 1;
     }
     // where every column will live: an extended coset already in HBM is used in place, anything else gets arena space
-    struct Upload { Fe* dst; const uint64_t* src; size_t elems; };
-    std::vector<Upload> uploads;  // host -> device column copies, issued after the metadata
+    struct Upload { Fe* dst; const uint64_t* src; size_t elems; bool late; };
+    std::vector<Upload> uploads;  // host -> device column copies, issued after the metadata; `late`: only the permutation kernel reads it
     bool bad = false;
-    auto place = [&](const uint64_t* h, size_t elems) -> Fe* {
+    auto place = [&](const uint64_t* h, size_t elems, bool late = false) -> Fe* {
         if (!h) {
             bad = true;
             return nullptr;
         }
         if (dev && elems == size) return (Fe*)h;
+        if (!dev && elems == size)  // a proving key's constant column the caller pinned (h2hip_columns_pin): already in HBM, fingerprint checked
+            if (const Fe* hit = pinned_column_lookup(c, h, elems)) return (Fe*)hit;
         Fe* p = (Fe*)ar.take(col_bytes);
         if (!p) bad = true;
-        else if (!dev) uploads.push_back({p, h, elems});
+        else if (!dev) uploads.push_back({p, h, elems, late});
         return p;
     };
     std::vector<const Fe*> fixed(d->n_fixed), advice(d->n_advice), instance(d->n_instance);
@@ -1191,7 +1193,7 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         Fe* p = (Fe*)ar.take(col_bytes);
         if (!p || !h) bad = true;
         if (dev) poly_src[i] = (const Fe*)h;  // the first NTT pass reads the coefficients where they lie
-        else uploads.push_back({p, h, n});
+        else uploads.push_back({p, h, n, false});
         poly_dst[i] = p;
         (i < d->n_advice ? advice[i] : instance[i - d->n_advice]) = p;
     }
@@ -1201,9 +1203,9 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
     Fe* const d_values = place(values, size);
     std::vector<const Fe*> z(d->n_perm_sets), pcols(d->n_perm_sets ? d->n_perm_columns : 0), pcosets(d->n_perm_sets ? d->n_perm_columns : 0);
     if (d->n_perm_sets) {
-        for (uint32_t i = 0; i < d->n_perm_sets; i++) z[i] = place(d->perm_product_cosets[i], size);
+        for (uint32_t i = 0; i < d->n_perm_sets; i++) z[i] = place(d->perm_product_cosets[i], size, true);
         for (uint32_t j = 0; j < d->n_perm_columns; j++) {
-            pcosets[j] = place(d->perm_cosets[j], size);
+            pcosets[j] = place(d->perm_cosets[j], size, true);
             const uint32_t kind = d->perm_column_kind[j], idx = d->perm_column_index[j];
             pcols[j] = kind == H2HIP_ANY_ADVICE ? advice[idx] : kind == H2HIP_ANY_FIXED ? fixed[idx] : instance[idx];  // :404-408
         }
@@ -1221,7 +1223,7 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
             for (int t = 0; t < 3; t++) {
                 poly_dst.push_back(lbuf[3 * i + t]);
                 poly_src.push_back(dev ? (const Fe*)lookup_poly((uint32_t)i, t) : nullptr);
-                if (!dev) uploads.push_back({lbuf[3 * i + t], lookup_poly((uint32_t)i, t), n});
+                if (!dev) uploads.push_back({lbuf[3 * i + t], lookup_poly((uint32_t)i, t), n, false});
             }
     if (bad) {
         set_error("evaluate_h: null column or arena overflow");
@@ -1275,7 +1277,15 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
     }
     // ---- columns: host -> device copies (host-pointer form), then advice / instance polynomials -> extended cosets
     //      (:306-323) in one batched transform: distribute_powers_zeta(into_coset) + zero-pad + NTT, as h2hip_coeff_to_extended does
-    for (const Upload& u : uploads) H2_CHECK(hipMemcpyAsync(u.dst, u.src, u.elems * sizeof(Fe), hipMemcpyHostToDevice, s));
+    // (the permutation argument's own columns -- the product cosets of this proof, and the key's permutation cosets when they are not
+    // pinned -- cross later, on a second stream under the coset transforms and the gates kernel: a copy from pageable memory blocks the
+    // calling thread, not the kernels already queued)
+    bool any_late = false;
+    for (const Upload& u : uploads) {
+        if (u.late) any_late = true;
+        else H2_CHECK(hipMemcpyAsync(u.dst, u.src, u.elems * sizeof(Fe), hipMemcpyHostToDevice, s));
+    }
+    if (any_late && (rc = c->ensure_aux(2))) return rc;
     NttScale sc;
     sc.in_scale = true;
     sc.in3[0] = fe_one<FrP>();
@@ -1311,6 +1321,12 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
     c->timer_end(t_g, s);
 
     // ---- permutations (:362-441)
+    if (any_late) {
+        for (const Upload& u : uploads)
+            if (u.late) H2_CHECK(hipMemcpyAsync(u.dst, u.src, u.elems * sizeof(Fe), hipMemcpyHostToDevice, c->aux2));
+        H2_CHECK(hipEventRecord(c->aux_events[0], c->aux2));
+        H2_CHECK(hipStreamWaitEvent(s, c->aux_events[0], 0));
+    }
     if (d->n_perm_sets) {
         int t_p = c->timer_begin("evalh_perm", s);
         hipLaunchKernelGGL(evalh_perm_kernel, grid, block, 0, s, pd, cols, d_values);

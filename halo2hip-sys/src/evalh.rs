@@ -305,6 +305,25 @@ pub fn try_evaluate_h<F: 'static + Copy>(inp: &EvalHInput<'_, F>, values: &mut [
         lookup_permuted_input_polys: lk_in.as_ptr(),
         lookup_permuted_table_polys: lk_tab.as_ptr(),
     };
+    // The proving key's own columns -- pk.fixed_cosets, pk.l0 / l_last / l_active_row, pk.permutation.cosets -- do not change from proof to
+    // proof: keep them in HBM across calls (idempotent; fingerprint-guarded like the pinned bases; a failure only means they are uploaded
+    // per call).  `unpin_key_columns` in ProvingKey's Drop (patch 0006) releases them.
+    let mut key_columns: Vec<*const u64> = fixed.clone();
+    key_columns.extend_from_slice(&perm_cosets);
+    key_columns.push(desc.l0);
+    key_columns.push(desc.l_last);
+    key_columns.push(desc.l_active_row);
+    let _ = unsafe { super::ffi::h2hip_columns_pin(key_columns.as_ptr(), key_columns.len(), en) };
     let rc: c_int = unsafe { super::ffi::h2hip_evaluate_h_bn254(&desc as *const h2hip_evalh_desc, values.as_mut_ptr() as *mut u64) };
     rc == 0
+}
+
+/// Release the device copies `try_evaluate_h` keeps of a proving key's constant columns (call from `ProvingKey`'s `Drop`, before the
+/// `Vec`s are freed; unknown pointers are ignored, other element types are a no-op).
+pub fn unpin_key_columns<F: 'static>(columns: &[&[F]]) {
+    if std::any::TypeId::of::<F>() != std::any::TypeId::of::<halo2curves::bn256::Fr>() || columns.is_empty() {
+        return;
+    }
+    let ptrs: Vec<*const u64> = columns.iter().map(|c| c.as_ptr() as *const u64).collect();
+    unsafe { super::ffi::h2hip_columns_unpin(ptrs.as_ptr(), ptrs.len()) };
 }

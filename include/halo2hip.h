@@ -318,6 +318,16 @@ typedef struct {
     const uint64_t* const* lookup_permuted_table_polys;
 } h2hip_evalh_desc;
 
+/* The constant columns of a proving key -- pk.fixed_cosets, pk.l0 / l_last / l_active_row, pk.permutation.cosets (plonk.rs:262-272): extended-coset
+ * form, `elems` = 2^extended_k elements each -- kept in HBM across h2hip_evaluate_h_bn254 calls, keyed by their host pointers: the host-pointer
+ * evaluate_h then uploads only what changes from proof to proof (at k = 18 in the bench system 22 of its 27 full-size columns are constant:
+ * 2.8 of 3.5 GB per call).  Idempotent; guarded like h2hip_bases_pin (16 sampled elements of the caller's memory are compared on every use, a
+ * mismatch drops the copy and uploads); HALO2_HIP_COLUMN_CACHE_GB (default 64) bounds the HBM taken, least recently used columns go first.
+ * Unpin before the Vecs are dropped (ProvingKey's Drop); unknown pointers are ignored; neither call changes any result. */
+int h2hip_columns_pin(const uint64_t* const* cols, size_t count, size_t elems);
+int h2hip_columns_unpin(const uint64_t* const* cols, size_t count);
+int h2hip_columns_pinned_info(size_t* n_columns, size_t* device_bytes);
+
 /* values: 2^extended_k elements, in/out, host memory; every column pointer in desc is host memory */
 int h2hip_evaluate_h_bn254(const h2hip_evalh_desc* desc, uint64_t* values);
 /* Device-resident form for a prover whose columns already live in HBM: every column pointer in desc (fixed_cosets[i],

@@ -118,7 +118,7 @@ def test_crate_sources_are_complete():
 @pytest.mark.skipif(not os.path.isdir(REF) or shutil.which("patch") is None, reason="needs the reference tree and patch(1)")
 def test_patches_apply_to_the_reference(tmp_path):
     patches = sorted(f for f in os.listdir(os.path.join(ROOT, "patches")) if f.endswith(".patch"))
-    assert len(patches) >= 5
+    assert len(patches) >= 6
     touched = set()
     for p in patches:
         for line in open(os.path.join(ROOT, "patches", p)):
@@ -126,7 +126,7 @@ def test_patches_apply_to_the_reference(tmp_path):
                 touched.add(line[6:].strip())
     assert {"halo2_proofs/src/arithmetic.rs", "halo2_proofs/src/poly/kzg/commitment.rs", "halo2_proofs/src/plonk/evaluation.rs",
             "halo2_proofs/Cargo.toml", "halo2_proofs/src/poly/domain.rs", "halo2_proofs/src/plonk/prover.rs",
-            "halo2_proofs/src/poly/commitment.rs", "halo2_proofs/src/plonk/vanishing/prover.rs"} <= touched
+            "halo2_proofs/src/poly/commitment.rs", "halo2_proofs/src/plonk/vanishing/prover.rs", "halo2_proofs/src/plonk.rs"} <= touched
     for rel in touched:  # a scratch copy of just those files (nothing of the reference enters the repository)
         dst = tmp_path / rel
         dst.parent.mkdir(parents=True, exist_ok=True)
@@ -158,6 +158,9 @@ def test_patches_apply_to_the_reference(tmp_path):
     assert kzg.count("halo2hip_sys::try_multiexp_batch::<E::G1Affine>(") == 2
     trait = (tmp_path / "halo2_proofs/src/poly/commitment.rs").read_text()
     assert "fn commit_lagrange_batch(" in trait and "fn commit_batch(" in trait
+    # 0006: the proving key releases the device copies of its constant columns
+    plonk = (tmp_path / "halo2_proofs/src/plonk.rs").read_text()
+    assert "impl<C: CurveAffine> Drop for ProvingKey<C>" in plonk and "halo2hip_sys::evalh::unpin_key_columns(&columns)" in plonk
     # every halo2hip_sys item the patches call exists in the crate
     called = set()
     for p in patches:

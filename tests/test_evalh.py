@@ -606,3 +606,43 @@ def test_generated_kernel_disk_cache_across_processes(tmp_path):
     assert first["match"] and second["match"]
     assert first["disk_hits"] == 0 and first["compiled"] == 1 and first["launches"] >= 1 and len(first["files"]) == 1 and first["files"][0].endswith("_gfx950.co")
     assert second["disk_hits"] == 1 and second["launches"] >= 1 and second["files"] == first["files"]
+
+
+@pytest.mark.gpu
+def test_gpu_evaluate_h_with_pinned_key_columns(h2, oracle):
+    """h2hip_columns_pin: the proving key's constant columns (fixed cosets, l0 / l_last / l_active_row, permutation cosets) stay in HBM across
+    host-pointer evaluate_h calls.  Same values as the oracle with and without the pins; pinning is idempotent; a column whose memory was
+    rewritten (what a freed and reused Vec looks like) is noticed and uploaded again; unpin releases everything and ignores strangers."""
+    h2.init()
+    case, vin = _random_case(oracle, 9, seed=31)
+    h = DescHolder(case)
+    want = vin.copy()
+    assert oracle.lib().oracle_evaluate_h(h.byref(), want.ctypes.data_as(ctypes.c_void_p)) == 0
+
+    def run():
+        got = vin.copy()
+        assert h2.lib().h2hip_evaluate_h_bn254(h.byref(), got.ctypes.data_as(ctypes.c_void_p)) == 0, h2.lib().h2hip_last_error()
+        return got
+
+    assert np.array_equal(run(), want)
+    key_cols = list(case["fixed_cosets"]) + list(case["perm_cosets"]) + [case["l0"], case["l_last"], case["l_active_row"]]
+    key_cols = [c_ for c_ in key_cols if c_.shape[0] == 1 << case["extended_k"]]
+    before = h2.columns_pinned_info()
+    h2.columns_pin(key_cols)
+    h2.columns_pin(key_cols)  # idempotent
+    n_pinned, nbytes = h2.columns_pinned_info()
+    assert n_pinned == before[0] + len(key_cols) and nbytes == before[1] + len(key_cols) * (32 << case["extended_k"])
+    assert np.array_equal(run(), want) and np.array_equal(run(), want)
+    # a pinned column's memory now holds other values (its first element is among the sampled ones): the stale copy must not be used
+    victim = case["fixed_cosets"][0]
+    saved = victim.copy()
+    victim[:] = oracle.gen_scalars(4242, victim.shape[0], num_threads=4)
+    want2 = vin.copy()
+    assert oracle.lib().oracle_evaluate_h(h.byref(), want2.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert np.array_equal(run(), want2) and not np.array_equal(want2, want)
+    assert h2.columns_pinned_info()[0] == n_pinned - 1  # the lookup dropped the stale entry
+    victim[:] = saved
+    assert np.array_equal(run(), want)
+    h2.columns_unpin(key_cols + [vin])  # a pointer that was never pinned is ignored
+    assert h2.columns_pinned_info() == before
+    assert np.array_equal(run(), want)

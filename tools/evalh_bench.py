@@ -55,7 +55,7 @@ def bench(args):
            "custom_calcs": len(evaluator.custom_gates.calculations), "custom_intermediates": evaluator.custom_gates.num_intermediates,
            "custom_rotations": len(evaluator.custom_gates.rotations)}
 
-    def run(k, check, time_cpu):
+    def run(k, check, time_cpu, host_timing=False):
         ek = k + 2
         n, size = 1 << k, 1 << ek
         d, _ = orc.domain_new(4, k)
@@ -109,7 +109,7 @@ def bench(args):
         call()
         torch.cuda.synchronize()
         res = {}
-        if check or time_cpu:
+        if check or time_cpu or host_timing:
             case_h = dict(case)
             for key in ("fixed_cosets", "advice_polys", "perm_product_cosets", "perm_cosets"):
                 case_h[key] = [host(t) for t in cols[key]]
@@ -117,6 +117,32 @@ def bench(args):
                 case_h[key] = host(cols[key])
             case_h["lookups"] = [tuple(host(t) for t in l) for l in cols["lookups"]]
             hh = evaluator.describe(case_h)
+        if host_timing:
+            # the host-pointer call (what patch 0003's evaluate_h_gpu makes: every column a Vec<F>), PCIe included, without and with the
+            # proving key's constant columns pinned in HBM (h2hip_columns_pin: fixed cosets, l0 / l_last / l_active_row, permutation cosets)
+            vals = host(v0).copy()
+
+            def host_call():
+                np.copyto(vals, host(v0))
+                t0 = time.perf_counter()
+                assert L.h2hip_evaluate_h_bn254(hh.byref(), vals.ctypes.data_as(ctypes.c_void_p)) == 0, L.h2hip_last_error()
+                return (time.perf_counter() - t0) * 1e3
+
+            def med(nrep=5):
+                host_call()
+                return float(np.median([host_call() for _ in range(nrep)]))
+
+            key_cols = list(case_h["fixed_cosets"]) + list(case_h["perm_cosets"]) + [case_h["l0"], case_h["l_last"], case_h["l_active_row"]]
+            full = 32 << ek
+            n_full = len(key_cols) + len(case_h["perm_product_cosets"]) + 1
+            res["host_pointer"] = {"ms_per_call_unpinned": med(), "full_size_columns": n_full, "key_columns": len(key_cols),
+                                   "upload_MiB_unpinned": (n_full * full + (args.advice + 3 * args.lookups) * (32 << k)) / 2**20}
+            h2.columns_pin(key_cols)
+            res["host_pointer"]["ms_per_call_key_columns_pinned"] = med()
+            res["host_pointer"]["upload_MiB_pinned"] = ((n_full - len(key_cols)) * full + (args.advice + 3 * args.lookups) * (32 << k)) / 2**20
+            res["host_pointer"]["pinned_bytes"] = h2.columns_pinned_info()[1]
+            h2.columns_unpin(key_cols)
+        if check or time_cpu:
             want = host(v0).copy()
             t0 = time.perf_counter()
             assert orc.lib().oracle_evaluate_h(hh.byref(), want.ctypes.data_as(ctypes.c_void_p)) == 0
@@ -186,11 +212,13 @@ def bench(args):
     if args.check_k:
         out["check_k%d" % args.check_k] = run(args.check_k, True, False)
     out["k%d" % args.k] = run(args.k, False, args.cpu)
+    if getattr(args, "host_k", 0):
+        out["host_k%d" % args.host_k] = {k_: v for k_, v in run(args.host_k, False, False, host_timing=True).items() if k_ in ("host_pointer", "gpu_ms")}
     return out
 
 
 def default_args(**over):
-    ns = argparse.Namespace(k=18, check_k=12, gates=24, advice=12, fixed=10, perm=9, lookups=2, iters=5, cpu=False)
+    ns = argparse.Namespace(k=18, check_k=12, gates=24, advice=12, fixed=10, perm=9, lookups=2, iters=5, cpu=False, host_k=16)
     for key, v in over.items():
         setattr(ns, key, v)
     return ns
@@ -207,6 +235,7 @@ def main():
     ap.add_argument("--lookups", type=int, default=2)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--cpu", action="store_true", help="time the oracle at --k too (single thread)")
+    ap.add_argument("--host-k", type=int, default=16, help="also time the host-pointer call at this k, with and without the key's columns pinned (0 = skip)")
     args = ap.parse_args()
     print(json.dumps(bench(args)))
 
