@@ -2106,11 +2106,7 @@ extern "C" int h2hip_columns_pin(const uint64_t* const* cols, size_t count, size
     if (en.rc) return en.rc;
     Ctx* c = en.c;  // evaluate_h runs on the engine's first device
     const size_t bytes = elems * sizeof(Fe);
-    size_t budget;
-    {
-        std::shared_lock<std::shared_mutex> lk(g_engine_mu);
-        budget = g_cfg.column_cache_bytes;
-    }
+    const size_t budget = g_cfg.column_cache_bytes;  // (the Entry above holds the engine lock shared: the configuration cannot change under it)
     for (size_t i = 0; i < count; i++) {
         if (pinned_column_lookup(c, cols[i], elems)) continue;  // already there (and still the same array)
         while (!c->pinned_cols.empty() && c->pinned_cols_bytes + bytes > budget) {  // least recently used first

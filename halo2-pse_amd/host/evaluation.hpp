@@ -353,7 +353,24 @@ class Evaluator {  // :182-189
         desc.lookup_product_polys = lprod.data();
         desc.lookup_permuted_input_polys = lpin.data();
         desc.lookup_permuted_table_polys = lptab.data();
+        {   // the proving key's constant columns stay in HBM across calls (as halo2hip-sys' try_evaluate_h does; `release_key_columns` below
+            // is the counterpart of patch 0006's Drop); a failure only means they are uploaded per call
+            std::vector<const uint64_t*> key = fixed;
+            key.insert(key.end(), pcosets.begin(), pcosets.end());
+            key.push_back(desc.l0);
+            key.push_back(desc.l_last);
+            key.push_back(desc.l_active_row);
+            (void)h2hip_columns_pin(key.data(), key.size(), size);
+        }
         engine_check(h2hip_evaluate_h_bn254(&desc, values[0].l), "h2hip_evaluate_h_bn254");
+    }
+
+    // ProvingKey's Drop (patch 0006): release the device copies of the key's constant columns
+    static void release_key_columns(const std::vector<const std::vector<Fr>*>& columns) {
+        std::vector<const uint64_t*> ptrs;
+        for (auto* c : columns)
+            if (c && !c->empty()) ptrs.push_back((*c)[0].l);
+        if (!ptrs.empty()) (void)h2hip_columns_unpin(ptrs.data(), ptrs.size());
     }
 };
 

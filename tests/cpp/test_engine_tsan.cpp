@@ -91,6 +91,23 @@ int main() {
                     for (size_t i = 0; i < m * 4; i += 97) CHECK(cols[j][i] == (uint64_t)(it * 1000 + j * 10) + i + 1);
             }
         });
+    // pinned proving-key columns: pin (idempotent), look at the cache, unpin, from two threads with their own columns
+    for (int t = 0; t < 2; t++)
+        th.emplace_back([&, t] {
+            const size_t m = 1 << 9;
+            std::vector<std::vector<uint64_t>> cols(4, std::vector<uint64_t>(m * 4, (uint64_t)(t + 1)));
+            const uint64_t* ptrs[4];
+            for (int j = 0; j < 4; j++) ptrs[j] = cols[j].data();
+            for (int it = 0; it < 40; it++) {
+                CHECK(h2hip_columns_pin(ptrs, 4, m) == 0);
+                CHECK(h2hip_columns_pin(ptrs, 4, m) == 0);
+                size_t nc = 0, nb = 0;
+                CHECK(h2hip_columns_pinned_info(&nc, &nb) == 0 && nc >= 4 && nb >= 4 * m * 32);
+                cols[it % 4][0] ^= 0x55;  // a rewritten column: the next pin drops the stale copy and uploads again
+                CHECK(h2hip_columns_pin(ptrs, 4, m) == 0);
+                CHECK(h2hip_columns_unpin(ptrs, 4) == 0);
+            }
+        });
     // the getters the shim calls on every best_multiexp / best_fft
     th.emplace_back([&] {
         while (!stop.load()) {
@@ -104,7 +121,7 @@ int main() {
     th.emplace_back([&] {
         for (int it = 0; it < 50; it++) CHECK(h2hip_init(ids, 2) == 0);
     });
-    for (size_t i = 0; i + 2 < th.size(); i++) th[i].join();
+    for (size_t i = 0; i + 2 < th.size(); i++) th[i].join();  // (the last two threads are the getters loop and the re-init loop)
     stop.store(true);
     th[th.size() - 2].join();
     th[th.size() - 1].join();
