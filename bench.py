@@ -73,12 +73,13 @@ def pmc_traffic(workload):
         return None
 
 
-def measure_traffic(log_n, form, kernel="msm_accum_kernel", timeout=100):
-    """HBM bytes per launch of the dominant kernel, measured by THIS run: two child processes under `rocprofv3 --pmc` (FETCH_SIZE and
+def measure_traffic(child_flags, kernels, timeout=100):
+    """HBM bytes per launch of the named kernels, measured by THIS run: two child processes under `rocprofv3 --pmc` (FETCH_SIZE and
     WRITE_SIZE in separate passes, no trace domain in either, as the MI355X guide's HBM section prescribes), each running nothing but
-    the timed step (`bench.py --only-step`).  Counter units are KiB; the read side takes factor 1 for this kernel (per-lane 64-B gathers:
-    the raw counter already exceeds the known gather volume, see profiles/pmc_traffic.json's note), WRITE_SIZE is exact.  Returns a dict
-    or None when rocprofv3 is missing or a pass fails (the committed figure then stands in, labelled as such)."""
+    one leg of this file (`bench.py --only-step` / `--only-ntt`).  kernels: [(name substring, read factor)] -- counter units are KiB;
+    the guide's x2 on FETCH_SIZE applies to wide coalesced reads (the NTT passes), per-lane 64-B gathers take factor 1 (the raw counter
+    already exceeds the known gather volume, profiles/pmc_traffic.json's note); WRITE_SIZE is exact.  Returns {name: dict} or None
+    when rocprofv3 is missing or a pass fails (the committed figure then stands in, labelled as such)."""
     import csv
     import glob
     import shutil
@@ -89,30 +90,39 @@ def measure_traffic(log_n, form, kernel="msm_accum_kernel", timeout=100):
     env = dict(os.environ, TMPDIR="/tmp")
     for k_ in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k_, None)
-    out = {}
+    raw = {name: {} for name, _ in kernels}
     tmp = tempfile.mkdtemp(prefix="h2pmc_", dir="/tmp")
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--only-step",
-                   "--log-n", str(log_n), "--form", form, "--steps", "5", "--warmup", "2", "--prewarm-ms", "0"]
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + list(child_flags)
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd="/tmp")
-            tot, n = 0.0, 0
+            if r.returncode != 0:
+                return None
+            acc = {name: [0.0, 0] for name, _ in kernels}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        if row.get("Counter_Name") == counter and kernel in row.get("Kernel_Name", ""):
-                            tot += float(row["Counter_Value"])
-                            n += 1
-            if r.returncode != 0 or n == 0:
-                return None
-            out[counter] = (tot / n * 1024.0, n)
+                        if row.get("Counter_Name") != counter:
+                            continue
+                        for name, _ in kernels:
+                            if name in row.get("Kernel_Name", ""):
+                                acc[name][0] += float(row["Counter_Value"])
+                                acc[name][1] += 1
+            for name, _ in kernels:
+                if acc[name][1] == 0:
+                    return None
+                raw[name][counter] = (acc[name][0] / acc[name][1] * 1024.0, acc[name][1])
     except (OSError, subprocess.SubprocessError, ValueError):
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return {"hbm_bytes_per_launch": out["FETCH_SIZE"][0] + out["WRITE_SIZE"][0], "read_bytes": out["FETCH_SIZE"][0], "write_bytes": out["WRITE_SIZE"][0],
-            "launches": [out["FETCH_SIZE"][1], out["WRITE_SIZE"][1]], "read_factor": 1.0}
+    out = {}
+    for name, factor in kernels:
+        rd, wr = raw[name]["FETCH_SIZE"][0] * factor, raw[name]["WRITE_SIZE"][0]
+        out[name] = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "read_factor": factor,
+                     "launches": [raw[name]["FETCH_SIZE"][1], raw[name]["WRITE_SIZE"][1]]}
+    return out
 
 
 def windows_of(c):
@@ -552,6 +562,14 @@ def main():
         ntt = ntt_point(args.ntt_log_n, 10)
         if solo and not args.no_cpu_baseline:
             ntt["cpu_baseline"] = ntt_cpu_baseline(args.ntt_log_n)
+        if solo and not args.no_measure_traffic and 19 <= args.ntt_log_n <= 22:  # the two-pass plan's kernels; re-observed by this run as well
+            live = measure_traffic(["--only-ntt", "--ntt-log-n", str(args.ntt_log_n)], [("ntt2_strided_kernel", 2.0), ("ntt2_final_kernel", 2.0)])
+            if live:
+                ntt["roofline"]["traffic_committed"] = ntt["roofline"]["traffic"]
+                ntt["roofline"]["traffic"] = live["ntt2_strided_kernel"]["hbm_bytes_per_launch"] + live["ntt2_final_kernel"]["hbm_bytes_per_launch"]
+                ntt["roofline"]["traffic_per_pass"] = live
+                ntt["roofline"]["traffic_source"] = ("measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE as two separate child passes of `bench.py --only-ntt` "
+                                                     "(one transform = ntt2_strided_kernel + ntt2_final_kernel; KiB counters, the guide's x2 on the wide coalesced reads)")
 
     # ---- the sizes DESIGN.md quotes, measured by this run (rank 0, N = 1) ----
     sizes = None
@@ -760,7 +778,9 @@ def main():
         accum_ms = accum_ms_live or stages.get("msm_accum")
         roof = msm_roofline(n, accum_ms, "msm_2p%d_%s" % (args.log_n, args.form)) if accum_ms else None
         if roof and solo and not args.no_measure_traffic:  # the dominant kernel's HBM bytes, re-observed by this run
-            live = measure_traffic(args.log_n, args.form)
+            live = measure_traffic(["--only-step", "--log-n", str(args.log_n), "--form", args.form, "--steps", "5", "--warmup", "2", "--prewarm-ms", "0"],
+                                   [("msm_accum_kernel", 1.0)])
+            live = live and live["msm_accum_kernel"]
             if live:
                 roof["traffic_committed"] = roof["traffic"]
                 roof["traffic"] = live["hbm_bytes_per_launch"]
