@@ -134,8 +134,9 @@ __device__ __forceinline__ void round_sync(uint32_t next_log_h, bool next_is_rad
 // R-point DFT on J columns held in LDS as x[col*R + bitrev(r)] on entry, x[col*R + k] on exit (decimation in
 // time).  Two butterfly stages per LDS round trip: a lane takes the four elements base + {0, h, 2h, 3h}, runs
 // the stage of half-size h on (x0,x1), (x2,x3) and the stage of half-size 2h on (y0,y2), (y1,y3) in registers.
-// Every stage multiplies by its twiddle, w^0 = 1 included (keeps |value| growing by at most ~1.3 r per stage
-// instead of doubling), except stage 0 whose twiddles are all 1 and whose inputs are fresh; limbs are
+// Every stage multiplies by its twiddle, w^0 = 1 included (keeps |value| growing by at most ~1.2 r per stage
+// instead of doubling), except in the first round, whose inputs are fresh: stage 0's twiddles are all 1 and so
+// is one of stage 1's two (four fresh values add up to < 4.5 r; the canonicalising store accepts 16 r); limbs are
 // re-normalised after each stage pair, which keeps every fu_mul operand below 2^30.  An odd s ends with one
 // single stage whose loose outputs the canonicalising store accepts.
 __device__ __forceinline__ void dft_lds(Fu* x, const Fu* wtab, uint32_t s, uint32_t log_j) {
@@ -159,7 +160,7 @@ __device__ __forceinline__ void dft_lds(Fu* x, const Fu* wtab, uint32_t s, uint3
                 x3 = fu_mul<FrUA>(x3, wa);
             }
             Fu y0 = fu_add(x0, x1), y1 = fu_sub(x0, x1), y2 = fu_add(x2, x3), y3 = fu_sub(x2, x3);
-            Fu u2 = fu_mul<FrUA>(y2, wtab[off << (s - 2 - log_h)]);
+            Fu u2 = log_h ? fu_mul<FrUA>(y2, wtab[off << (s - 2 - log_h)]) : y2;  // first round: the twiddle is 1 (dft_col's note on the bound)
             Fu u3 = fu_mul<FrUA>(y3, wtab[(off + h) << (s - 2 - log_h)]);
             x[base] = fu_norm(fu_add(y0, u2));
             x[e2] = fu_norm(fu_sub(y0, u2));
@@ -278,33 +279,27 @@ template <bool OWN = false>
 __device__ __forceinline__ void dft_col(Fu* x, const Fu* wtab, uint32_t s, const Fu (&v)[4], Fu (&res)[4], bool quarter = false) {
     const uint32_t t = threadIdx.x;
     const uint32_t b0 = lds_swz((OWN ? t : bitrev(t, s - 2)) << 2);  // swz(4 i' + j) = swz(4 i') ^ j
-    uint32_t log_h;
-    if (!(s & 1) && quarter) {
+    // stages 0 and 1 on the loaded values.  Stage 0's twiddles are all 1 and stage 1's are 1 and w_4: the product by 1 is not formed (the sum
+    // of four fresh values stays below 4.5 p -- the rounds that follow add at most 2.3 p each, the canonicalising store takes 16 p -- and
+    // below 2^31 per limb).  An odd s ends with a lone stage instead (below): 19 instead of 20 multiplications per lane at s = 11.
+    if (quarter) {
         const Fu n0 = fu_norm(v[0]);
         x[b0] = n0;
         x[b0 ^ 1] = n0;
         x[b0 ^ 2] = n0;
         x[b0 ^ 3] = n0;
-        log_h = 2;
-    } else if (s & 1) {
-        x[b0] = fu_norm(fu_add(v[0], v[2]));
-        x[b0 ^ 1] = fu_norm(fu_sub(v[0], v[2]));
-        x[b0 ^ 2] = fu_norm(fu_add(v[1], v[3]));
-        x[b0 ^ 3] = fu_norm(fu_sub(v[1], v[3]));
-        log_h = 1;
     } else {
         const Fu y0 = fu_add(v[0], v[2]), y1 = fu_sub(v[0], v[2]), y2 = fu_add(v[1], v[3]), y3 = fu_sub(v[1], v[3]);
-        const Fu u2 = fu_mul<FrUA>(y2, wtab[0]);
         const Fu u3 = fu_mul<FrUA>(y3, wtab[1u << (s - 2)]);
-        x[b0] = fu_norm(fu_add(y0, u2));
-        x[b0 ^ 2] = fu_norm(fu_sub(y0, u2));
+        x[b0] = fu_norm(fu_add(y0, y2));
+        x[b0 ^ 2] = fu_norm(fu_sub(y0, y2));
         x[b0 ^ 1] = fu_norm(fu_add(y1, u3));
         x[b0 ^ 3] = fu_norm(fu_sub(y1, u3));
-        log_h = 2;
     }
-    if (OWN) round_sync(log_h, true);
+    uint32_t log_h = 2;
+    if (OWN) round_sync(log_h, log_h + 2 <= s);
     else __syncthreads();
-    for (;; log_h += 2) {
+    for (; log_h + 2 <= s; log_h += 2) {
         const bool last = log_h + 2 == s;
         const uint32_t h = 1u << log_h;
         const uint32_t d1 = lds_swz(h), d2 = lds_swz(2 * h), d3 = d1 ^ d2;
@@ -329,7 +324,17 @@ __device__ __forceinline__ void dft_col(Fu* x, const Fu* wtab, uint32_t s, const
         x[e2] = fu_norm(fu_sub(y0, u2));
         x[e1] = fu_norm(fu_add(y1, u3));
         x[e3] = fu_norm(fu_sub(y1, u3));
-        round_sync(log_h + 2, true);
+        round_sync(log_h + 2, log_h + 4 <= s);
+    }
+    if (s & 1) {  // the lone last stage, half-size R / 2: the lane's own outputs t + m R/4 pair up as (0, 2) and (1, 3)
+        const uint32_t q = 1u << (s - 2);
+        const Fu a0 = x[lds_swz(t)], a1 = x[lds_swz(t + q)];
+        const Fu t0 = fu_mul<FrUA>(x[lds_swz(t + 2 * q)], wtab[t]);
+        const Fu t1 = fu_mul<FrUA>(x[lds_swz(t + 3 * q)], wtab[t + q]);
+        res[0] = fu_add(a0, t0);
+        res[2] = fu_sub(a0, t0);
+        res[1] = fu_add(a1, t1);
+        res[3] = fu_sub(a1, t1);
     }
     __syncthreads();  // the image is free for the next column
 }
