@@ -45,8 +45,9 @@ FIELD_MUL_PER_BUCKET_ADD = 9.2  # XYZZ mixed add: 7 products + 2 squares + one t
 FIELD_MUL_PEAK_G = 179.0  # measured peak of csrc/fieldu.cuh's multiplier on MI355X, G multiplies/s (tools/mul_rate.hip)
 # Fr multiplications per element of one transform: (log2 n) / 2 butterfly products, plus per pass boundary one to apply the
 # inter-pass twiddle and -- where it is combined from the two-level table instead of read from a per-domain table -- one to combine it;
-# the closing reduction is not a multiplication.  2^22 on two passes: 11 + 2 = 13; 2^24 on three: 12 + 2.5 (one boundary reads a table) = 14.5
-NTT_FIELD_MUL_PER_ELEM = {20: 11.0, 22: 13.0, 24: 14.5, 26: 15.5}
+# the closing reduction is not a multiplication; each pass's first round forms one product fewer per four points (its twiddle is 1).
+# 2^22 on two passes: 11 + 2 - 0.5 = 12.5; 2^24 on three: 12 + 2.5 (one boundary reads a table) - 0.75 = 13.75
+NTT_FIELD_MUL_PER_ELEM = {20: 10.5, 22: 12.5, 24: 13.75, 26: 14.75}
 STAGES = ("msm_total", "msm_digits", "msm_sort", "msm_accum", "msm_reduce")  # over-full buckets are summed inside the accumulate launch
 
 
@@ -73,13 +74,10 @@ def pmc_traffic(workload):
         return None
 
 
-def measure_traffic(child_flags, kernels, timeout=100):
-    """HBM bytes per launch of the named kernels, measured by THIS run: two child processes under `rocprofv3 --pmc` (FETCH_SIZE and
-    WRITE_SIZE in separate passes, no trace domain in either, as the MI355X guide's HBM section prescribes), each running nothing but
-    one leg of this file (`bench.py --only-step` / `--only-ntt`).  kernels: [(name substring, read factor)] -- counter units are KiB;
-    the guide's x2 on FETCH_SIZE applies to wide coalesced reads (the NTT passes), per-lane 64-B gathers take factor 1 (the raw counter
-    already exceeds the known gather volume, profiles/pmc_traffic.json's note); WRITE_SIZE is exact.  Returns {name: dict} or None
-    when rocprofv3 is missing or a pass fails (the committed figure then stands in, labelled as such)."""
+def pmc_pass(child_flags, counters, names, timeout=100):
+    """One child process of this file under `rocprofv3 --pmc <counters>` (no trace domain), running nothing but one leg (`--only-step` /
+    `--only-ntt`).  Returns {kernel name substring: {counter: (mean per launch, launches)}} or None when rocprofv3 is missing, the pass
+    fails or a named kernel was not seen."""
     import csv
     import glob
     import shutil
@@ -90,38 +88,76 @@ def measure_traffic(child_flags, kernels, timeout=100):
     env = dict(os.environ, TMPDIR="/tmp")
     for k_ in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k_, None)
-    raw = {name: {} for name, _ in kernels}
     tmp = tempfile.mkdtemp(prefix="h2pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + list(child_flags)
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd="/tmp")
-            if r.returncode != 0:
+        cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + list(child_flags)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd="/tmp")
+        if r.returncode != 0:
+            return None
+        acc = {name: {c_: [0.0, 0] for c_ in counters} for name in names}
+        for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    c_ = row.get("Counter_Name")
+                    if c_ not in counters:
+                        continue
+                    for name in names:
+                        if name in row.get("Kernel_Name", ""):
+                            acc[name][c_][0] += float(row["Counter_Value"])
+                            acc[name][c_][1] += 1
+        out = {}
+        for name in names:
+            if any(acc[name][c_][1] == 0 for c_ in counters):
                 return None
-            acc = {name: [0.0, 0] for name, _ in kernels}
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                with open(f) as fh:
-                    for row in csv.DictReader(fh):
-                        if row.get("Counter_Name") != counter:
-                            continue
-                        for name, _ in kernels:
-                            if name in row.get("Kernel_Name", ""):
-                                acc[name][0] += float(row["Counter_Value"])
-                                acc[name][1] += 1
-            for name, _ in kernels:
-                if acc[name][1] == 0:
-                    return None
-                raw[name][counter] = (acc[name][0] / acc[name][1] * 1024.0, acc[name][1])
+            out[name] = {c_: (acc[name][c_][0] / acc[name][c_][1], acc[name][c_][1]) for c_ in counters}
+        return out
     except (OSError, subprocess.SubprocessError, ValueError):
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def measure_traffic(child_flags, kernels, timeout=100):
+    """HBM bytes per launch of the named kernels, measured by THIS run: two child processes under `rocprofv3 --pmc` (FETCH_SIZE and
+    WRITE_SIZE in separate passes, no trace domain in either, as the MI355X guide's HBM section prescribes).  kernels: [(name substring,
+    read factor)] -- counter units are KiB; the guide's x2 on FETCH_SIZE applies to wide coalesced reads (the NTT passes), per-lane
+    64-B gathers take factor 1 (the raw counter already exceeds the known gather volume, profiles/pmc_traffic.json's note); WRITE_SIZE
+    is exact.  Returns {name: dict} or None (the committed figure then stands in, labelled as such)."""
+    names = [name for name, _ in kernels]
+    rd_ = pmc_pass(child_flags, ["FETCH_SIZE"], names, timeout)
+    wr_ = rd_ and pmc_pass(child_flags, ["WRITE_SIZE"], names, timeout)
+    if not wr_:
+        return None
     out = {}
     for name, factor in kernels:
-        rd, wr = raw[name]["FETCH_SIZE"][0] * factor, raw[name]["WRITE_SIZE"][0]
+        rd, wr = rd_[name]["FETCH_SIZE"][0] * 1024.0 * factor, wr_[name]["WRITE_SIZE"][0] * 1024.0
         out[name] = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "read_factor": factor,
-                     "launches": [raw[name]["FETCH_SIZE"][1], raw[name]["WRITE_SIZE"][1]]}
+                     "launches": [rd_[name]["FETCH_SIZE"][1], wr_[name]["WRITE_SIZE"][1]]}
+    return out
+
+
+N_SIMD = 256 * 4  # MI355X: 256 CUs x 4 SIMDs; a SIMD issues one wave64 vector instruction per four cycles
+
+
+def measure_issue(child_flags, names, timeout=100):
+    """Share of the chip's vector-issue slots the named kernels fill, measured by THIS run: one more `rocprofv3 --pmc` child pass with the
+    SQ counters.  SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count quad-cycles summed over the waves (MI355X guide, PMC table); GRBM_GUI_ACTIVE
+    is the kernel's busy cycles summed over the 8 XCDs.  issue_frac = SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 / 4): the
+    kernel's VALU instructions against one per SIMD per four cycles for as long as the chip was busy with it (GRBM_GUI_ACTIVE includes the
+    dispatch's ramp and reads a few % long on launches under ~0.3 ms -- the guide's note -- so the figure errs low).  Also: waves resident per
+    SIMD on average (SQ_WAVE_CYCLES over the same denominator) and the instructions per wave."""
+    ctr = ["SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAVES", "GRBM_GUI_ACTIVE"]
+    r = pmc_pass(child_flags, ctr, names, timeout)
+    if not r:
+        return None
+    out = {}
+    for name in names:
+        v = {c_: r[name][c_][0] for c_ in ctr}
+        slots = N_SIMD * v["GRBM_GUI_ACTIVE"] / 8.0 / 4.0
+        out[name] = {"issue_frac": v["SQ_ACTIVE_INST_VALU"] / slots, "waves_per_simd_resident": v["SQ_WAVE_CYCLES"] / slots,
+                     "valu_insts_per_wave": v["SQ_INSTS_VALU"] / v["SQ_WAVES"], "wave_parked_frac": v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"],
+                     "counters": v, "launches": r[name]["SQ_WAVES"][1],
+                     "source": "measured by this run: one rocprofv3 --pmc child pass (SQ counters, no trace domain); issue_frac = SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 / 4)"}
     return out
 
 
@@ -570,6 +606,9 @@ def main():
                 ntt["roofline"]["traffic_per_pass"] = live
                 ntt["roofline"]["traffic_source"] = ("measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE as two separate child passes of `bench.py --only-ntt` "
                                                      "(one transform = ntt2_strided_kernel + ntt2_final_kernel; KiB counters, the guide's x2 on the wide coalesced reads)")
+            iss = measure_issue(["--only-ntt", "--ntt-log-n", str(args.ntt_log_n)], ["ntt2_strided_kernel", "ntt2_final_kernel"])
+            if iss:
+                ntt["valu_roofline"]["issue_slots"] = iss
 
     # ---- the sizes DESIGN.md quotes, measured by this run (rank 0, N = 1) ----
     sizes = None
@@ -794,6 +833,10 @@ def main():
             gmul = n * W * FIELD_MUL_PER_BUCKET_ADD / (accum_ms * 1e-3) / 1e9
             valu = {"bound": "valu-int", "kernel": "msm_accum_kernel", "field_mul_per_add": FIELD_MUL_PER_BUCKET_ADD,
                     "achieved": gmul, "peak": FIELD_MUL_PEAK_G, "unit": "Gmul/s", "frac": gmul / FIELD_MUL_PEAK_G}
+        if valu and solo and not args.no_measure_traffic:  # and how full the vector-issue slots were while it ran (SQ counters, one more child pass)
+            iss = measure_issue(["--only-step", "--log-n", str(args.log_n), "--form", args.form, "--steps", "5", "--warmup", "2", "--prewarm-ms", "0"], ["msm_accum_kernel"])
+            if iss:
+                valu["issue_slots"] = iss["msm_accum_kernel"]
         out = {
             "metric": "bn254_msm_g1_adds_per_sec",
             "value": adds / elapsed,

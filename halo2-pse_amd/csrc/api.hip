@@ -49,6 +49,7 @@ void ntt_set_full_twiddle_budget(uint64_t bytes);
 void ntt_set_batch_bytes(uint64_t bytes);
 void ntt_set_two_pass_log_j(int v);
 void ntt_set_full_max_log_m(uint32_t v);
+void ntt_set_fold_tables(bool on);
 void ntt_set_two_pass_batch_wgs(uint64_t v);
 void msm_set_reserved_cus(uint32_t k);
 uint32_t msm_get_reserved_cus();
@@ -2467,9 +2468,15 @@ int h2hip_debug_set_ntt_two_pass_batch_wgs(uint64_t v) {
     return 0;
 }
 
-// tuning hook: the largest strided pass (log2 of its M) that reads its inter-pass twiddles from a table (0 = default 20)
+// tuning hook: the largest strided pass (log2 of its M) that reads its inter-pass twiddles from a table (0 = default 24)
 int h2hip_debug_set_ntt_full_max_log_m(uint32_t v) {
     ntt_set_full_max_log_m(v);
+    return 0;
+}
+
+// A/B hook: 0 = the inverse transform's 1/n is multiplied in by the last pass even where the first pass reads a table (rounds 1-3)
+int h2hip_debug_set_ntt_fold_tables(int on) {
+    ntt_set_fold_tables(on != 0);
     return 0;
 }
 

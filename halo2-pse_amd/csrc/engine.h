@@ -61,10 +61,13 @@ struct TwiddleTable {
     // two), and until round 4 every switch freed and rebuilt the other plan's tables behind a device-wide synchronisation.
     Fu* stage_of[13] = {};
     // the inter-pass twiddles of a pass as one table, when the budget allows (ntt.hip get_full_twiddles); tag = layout << 31 |
-    // log_m << 8 | s (layout 1: the two-pass plan's pass 1).  Up to H2_TW_FULL tables per domain, none is ever replaced.
-#define H2_TW_FULL 8
+    // scaled << 30 | log_m << 8 | s (layout 1: the two-pass plan's pass 1; scaled: every entry times full_scale[k], the 1/n of the inverse
+    // transform that uses this domain -- its last pass then closes with the direct reduction instead of a multiplication).  Up to
+    // H2_TW_FULL tables per domain, none is ever replaced.
+#define H2_TW_FULL 12
     Fu* full[H2_TW_FULL] = {};
     uint32_t full_tag[H2_TW_FULL] = {};
+    Fe full_scale[H2_TW_FULL] = {};
     // `lo` times one constant (the 1/n of the inverse transform that uses this domain): a first pass that combines its inter-pass
     // twiddles from the two-level table then scales for free, and the last pass closes with the direct reduction (ntt.hip ntt_run)
     Fu* lo_scaled = nullptr;

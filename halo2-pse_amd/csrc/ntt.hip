@@ -468,12 +468,17 @@ void ntt_twiddles_free(Ctx* c) {
     c->tw_full_bytes = 0;
 }
 
-static uint64_t g_ntt_full_budget = (uint64_t)1 << 30;  // HALO2_HIP_NTT_TWIDDLE_MB: HBM the full inter-pass tables may take per device
+static uint64_t g_ntt_full_budget = (uint64_t)4 << 30;  // HALO2_HIP_NTT_TWIDDLE_MB: HBM the full inter-pass tables may take per device (of 288 GB)
 void ntt_set_full_twiddle_budget(uint64_t bytes) { g_ntt_full_budget = bytes; }
 static size_t g_ntt_batch_bytes = (size_t)2 << 30;  // columns + workspace one batched launch may span (ntt_device_batch)
 void ntt_set_batch_bytes(uint64_t bytes) { g_ntt_batch_bytes = bytes ? (size_t)bytes : (size_t)2 << 30; }
-static uint32_t g_ntt_full_max_log_m = 20;  // strided passes of the three-pass plan read their inter-pass twiddles from a table up to 2^this entries
-void ntt_set_full_max_log_m(uint32_t v) { g_ntt_full_max_log_m = v ? v : 20; }
+// Strided passes of the three-pass plan read their inter-pass twiddles from a table of up to 2^this entries (36 B each: 0.3 / 0.6 GB per domain
+// and direction at 2^23 / 2^24 for the first pass's, 2.4 MB for the second's) while the budget lasts: one multiplication per point fewer than
+// combining the two-level table (2^23 -5 %, 2^24 -2.5 %; at 2^25 and beyond the pass has no memory bandwidth to spare for it and nothing is gained).
+static uint32_t g_ntt_full_max_log_m = 24;
+void ntt_set_full_max_log_m(uint32_t v) { g_ntt_full_max_log_m = v ? v : 24; }
+static bool g_ntt_fold_tables = true;  // the inverse's 1/n rides in a scaled copy of the first pass's table (A/B: h2hip_debug_set_ntt_fold_tables)
+void ntt_set_fold_tables(bool on) { g_ntt_fold_tables = on; }
 static int g_ntt2_log_j = -1;  // tuning: columns per workgroup of the two-pass kernels (-1 = the plan's choice)
 void ntt_set_two_pass_log_j(int v) { g_ntt2_log_j = v; }
 
@@ -585,7 +590,7 @@ static int get_stage_twiddles(Ctx* c, const Fe& omega, uint32_t log_n, uint32_t 
 // pass 1 (2^log_n entries [lo][k]: 38 MB at 2^20, 75 MB at 2^21); otherwise a strided pass of the other plan (2^log_m entries
 // [k][lo]).  `p` carries the two-level table, log_m and s.  *table stays null when the budget (or the domain's H2_TW_FULL slots)
 // is spent: the kernels fall back to tw_pow.
-static int get_full_twiddles(Ctx* c, const Fe& omega, const NttPass& p, bool two_pass, hipStream_t s, const Fu** table) {
+static int get_full_twiddles(Ctx* c, const Fe& omega, const NttPass& p, bool two_pass, hipStream_t s, const Fu** table, const Fe* scale = nullptr) {
     *table = nullptr;
     TwiddleKey key;
     for (int i = 0; i < 8; i++) key.omega[i] = omega.l[i];
@@ -594,16 +599,24 @@ static int get_full_twiddles(Ctx* c, const Fe& omega, const NttPass& p, bool two
     if (it == c->twiddles.end()) return 0;
     TwiddleTable& t = it->second;
     const size_t bytes = sizeof(Fu) << p.log_m;
-    const uint32_t tag = (two_pass ? 0x80000000u : 0u) | (p.log_m << 8) | p.s;
+    const uint32_t tag = (two_pass ? 0x80000000u : 0u) | (scale ? 0x40000000u : 0u) | (p.log_m << 8) | p.s;
     int free_slot = -1;
     for (int k = 0; k < H2_TW_FULL; k++) {
         if (t.full[k] && t.full_tag[k] == tag) {
-            *table = t.full[k];
+            // scaled: one constant per domain and pass (the inverse's 1/n); a caller with another one takes the unscaled table and multiplies
+            if (!scale || memcmp(&t.full_scale[k], scale, sizeof(Fe)) == 0) *table = t.full[k];
             return 0;
         }
         if (!t.full[k] && free_slot < 0) free_slot = k;
     }
     if (free_slot < 0 || c->tw_full_bytes + bytes > g_ntt_full_budget) return 0;
+    NttPass q = p;
+    if (scale) {  // built from the scaled copy of `lo`: tw_pow(q, e) = scale * omega^e for every e
+        const Fu* lo_s = nullptr;
+        int rc = get_scaled_lo(c, omega, p.log_n, *scale, s, &lo_s);
+        if (rc) return rc;
+        q.tw_lo = lo_s;
+    }
     Fu* d = nullptr;
     if (hipMalloc((void**)&d, bytes) != hipSuccess) {
         (void)hipGetLastError();  // no room: not an error, the two-level table still serves
@@ -611,13 +624,14 @@ static int get_full_twiddles(Ctx* c, const Fe& omega, const NttPass& p, bool two
     }
     const dim3 grid((uint32_t)((((uint64_t)1 << p.log_m) + 255) / 256));
     if (two_pass)
-        hipLaunchKernelGGL(full_twiddle_build_kernel, grid, dim3(256), 0, s, p, d);
+        hipLaunchKernelGGL(full_twiddle_build_kernel, grid, dim3(256), 0, s, q, d);
     else
-        hipLaunchKernelGGL(pass_twiddle_build_kernel, grid, dim3(256), 0, s, p, d);
+        hipLaunchKernelGGL(pass_twiddle_build_kernel, grid, dim3(256), 0, s, q, d);
     H2_CHECK(hipGetLastError());
     H2_CHECK(hipStreamSynchronize(s));
     t.full[free_slot] = d;
     t.full_tag[free_slot] = tag;
+    if (scale) t.full_scale[free_slot] = *scale;
     c->tw_full_bytes += bytes;
     *table = d;
     return 0;
@@ -795,7 +809,14 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
         // no longer do and the table costs 7 % instead
         p.log_m = log_n;
         const Fu* full0 = nullptr;
-        if (log_n <= 21 && g_ntt_full_budget && (rc = get_full_twiddles(c, omega, p, true, s, &full0))) return rc;
+        if (log_n <= 21 && g_ntt_full_budget) {
+            // one output constant (the inverse's 1/n): a copy of the table that carries it, and pass 2 closes with the direct reduction
+            if (p.out_scale == 2 && sc && g_ntt_fold_tables) {
+                if ((rc = get_full_twiddles(c, omega, p, true, s, &full0, &sc->out3[0]))) return rc;
+                folded = full0 != nullptr;
+            }
+            if (!full0 && (rc = get_full_twiddles(c, omega, p, true, s, &full0))) return rc;
+        }
         p.log_j = 0;  // one column / block per workgroup, neighbours grouped per XCD (ntt2_strided_kernel); two columns one after the other: see there
         if (g_ntt2_log_j >= 0 && g_ntt2_log_j <= 3) p.log_j = (uint32_t)g_ntt2_log_j;
         for (int t = 0; t < 2; t++) {
@@ -858,7 +879,11 @@ static int ntt_run(Ctx* c, size_t count, Fe* const* h_datas, const Fe* const* h_
             p.tw_lo = tw.lo;  // (before a table is built from it: pass_twiddle_build_kernel reads p)
             if (log_m <= g_ntt_full_max_log_m && g_ntt_full_budget) {
                 const Fu* full = nullptr;
-                if ((rc = get_full_twiddles(c, omega, p, false, s, &full))) return rc;
+                if (t == 0 && p.out_scale == 2 && sc && g_ntt_fold_tables) {  // as in the two-pass plan: the first pass's table carries the one output constant
+                    if ((rc = get_full_twiddles(c, omega, p, false, s, &full, &sc->out3[0]))) return rc;
+                    folded = full != nullptr;
+                }
+                if (!full && (rc = get_full_twiddles(c, omega, p, false, s, &full))) return rc;
                 p.tw_full = full;
             }
             if (t == 0 && !p.tw_full && p.out_scale == 2 && sc) {  // as in the two-pass plan: the one output constant rides in the first pass's twiddles

@@ -34,8 +34,8 @@
  * HALO2_HIP_TABLE_MAX_GB for h2hip_bases_pin's window tables; HALO2_HIP_MSM_MIN_N /
  * HALO2_HIP_NTT_MIN_LOGN thresholds the Rust shim reads back through h2hip_msm_min_n() /
  * h2hip_ntt_min_log_n(); HALO2_HIP_ROCTX=1 roctx ranges around every entry point;
- * HALO2_HIP_NTT_TWIDDLE_MB (default 1024) HBM per device for the full inter-pass twiddle tables of 2^20- and 2^21-point
- * transforms (36 bytes per point and domain; without room the two-level table serves, one multiplication more per point);
+ * HALO2_HIP_NTT_TWIDDLE_MB (default 4096) HBM per device for the full inter-pass twiddle tables of 2^20-, 2^21-, 2^23- and 2^24-point
+ * transforms (36 bytes per point, domain and direction; without room the two-level table serves, one multiplication more per point);
  * HALO2_HIP_LAZY_PIN=k (default 0 = off) lets the library pin a host bases array by itself once a
  * host-pointer MSM has seen it k times (see h2hip_bases_pin); HALO2_HIP_EVALH_CODEGEN=0|1|2 the per-circuit custom-gates kernel of
  * h2hip_evaluate_h_bn254 (0: byte-code interpreter only; 1, default: generated and compiled by hiprtc on a background thread, the interpreter

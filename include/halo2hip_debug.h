@@ -58,8 +58,10 @@ int h2hip_debug_set_ntt_twiddle_budget(uint64_t bytes);
 int h2hip_debug_set_ntt_batch_bytes(uint64_t bytes);
 /* two-pass plan for batched columns of 2^17 / 2^18 points: from this many pairs of workgroups per pass (0 = default 512) */
 int h2hip_debug_set_ntt_two_pass_batch_wgs(uint64_t v);
-/* three-pass plan: strided passes up to 2^v points read their inter-pass twiddles from a per-domain table (0 = default 20) */
+/* three-pass plan: strided passes up to 2^v points read their inter-pass twiddles from a per-domain table (0 = default 24) */
 int h2hip_debug_set_ntt_full_max_log_m(uint32_t v);
+/* 0: no scaled copies of the inter-pass tables (the inverse's 1/n is then a multiplication in the last pass); 1 = default */
+int h2hip_debug_set_ntt_fold_tables(int on);
 /* host-pointer batched transforms: device bytes one pipelined run may hold (0 = default 4 GB; smaller forces several runs) and the
  * size below which columns are grouped per pipeline step (0 = default 2 MB) */
 int h2hip_debug_set_ntt_host_batch(uint64_t run_bytes, uint64_t group_bytes);

@@ -31,6 +31,7 @@ void ntt_set_full_twiddle_budget(uint64_t) {}
 void ntt_set_batch_bytes(uint64_t) {}
 void ntt_set_two_pass_log_j(int) {}
 void ntt_set_full_max_log_m(uint32_t) {}
+void ntt_set_fold_tables(bool) {}
 void ntt_set_two_pass_batch_wgs(uint64_t) {}
 void msm_set_reserved_cus(uint32_t) {}
 uint32_t msm_get_reserved_cus() { return 0; }

@@ -241,10 +241,49 @@ def test_ntt_two_pass_plan_equals_three_pass(h2, oracle, k):
             out[plan] = (f, i, e, b)
     finally:
         L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(0), ctypes.c_uint32(0))
-        L.h2hip_debug_set_ntt_twiddle_budget(ctypes.c_uint64(1 << 30))
+        L.h2hip_debug_set_ntt_twiddle_budget(ctypes.c_uint64(4 << 30))
     for plan, res in out.items():
         for x, y in zip(res, out["three"]):
             assert torch.equal(x, y), plan
+
+
+@pytest.mark.parametrize("k", [11, 14, 17, 19, 20, 21, 23, 24])
+def test_inverse_scale_folded_into_the_first_pass_table(h2, oracle, k):
+    """round 4: where the first pass reads its inter-pass twiddles from a per-domain table, the inverse's 1/n rides in a scaled copy of
+    that table (get_full_twiddles(.., scale)) and the last pass closes with the direct reduction.  Same limbs as the multiplication in
+    the last pass (h2hip_debug_set_ntt_fold_tables(0)), lone and as a batch; a second constant on the same domain (not a prover's case)
+    finds the table taken, multiplies instead and is right as well; the round trip restores the input."""
+    import ctypes
+    import torch
+    L = h2.lib()
+    d, _ = oracle.domain_new(1, k)
+    a = h2.gen_scalars_device(4100 + k, 1 << k)
+    other = d.fe("omega")  # any second constant
+    try:
+        got = {}
+        for on in (1, 0):
+            L.h2hip_debug_set_ntt_fold_tables(ctypes.c_int(on))
+            x = a.clone()
+            h2.ifft_device(x, d.fe("omega_inv"), k, d.fe("ifft_divisor"))
+            y = a.clone()
+            h2.ifft_device(y, d.fe("omega_inv"), k, other)
+            cols = [a.clone() for _ in range(3)] if k <= 21 else []
+            if cols:
+                h2.ifft_batch_device(cols, d.fe("omega_inv"), k, d.fe("ifft_divisor"))
+            torch.cuda.synchronize()
+            got[on] = (x, y, cols)
+        assert torch.equal(got[1][0], got[0][0])
+        assert torch.equal(got[1][1], got[0][1])
+        for c1 in got[1][2] + got[0][2]:
+            assert torch.equal(c1, got[0][0])
+        back = got[1][0].clone()
+        h2.ntt_device(back, d.fe("omega"), k)
+        torch.cuda.synchronize()
+        assert torch.equal(back, a)
+        if k <= 17:
+            assert np.array_equal(h2.to_numpy_u64(got[1][0]), oracle.ifft(h2.to_numpy_u64(a).copy(), d.fe("omega_inv"), k, d.fe("ifft_divisor"), NT))
+    finally:
+        L.h2hip_debug_set_ntt_fold_tables(ctypes.c_int(1))
 
 
 @pytest.mark.parametrize("k", [6])

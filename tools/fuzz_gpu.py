@@ -65,7 +65,7 @@ for k in range(1, 23):
         torch.cuda.synchronize()
         outs.append((x, torch.equal(y, a)))
     L.h2hip_debug_set_ntt_two_pass(ctypes.c_uint32(0), ctypes.c_uint32(0))
-    L.h2hip_debug_set_ntt_twiddle_budget(ctypes.c_uint64(1 << 30))
+    L.h2hip_debug_set_ntt_twiddle_budget(ctypes.c_uint64(4 << 30))
     ok = all(torch.equal(o[0], outs[0][0]) and o[1] for o in outs)
     if k <= 16:
         ok = ok and np.array_equal(h2.to_numpy_u64(outs[0][0]), oracle.best_fft(h2.to_numpy_u64(a).copy(), d.omega, k, NT))
