@@ -71,6 +71,29 @@ for k in range(1, 23):
         ok = ok and np.array_equal(h2.to_numpy_u64(outs[0][0]), oracle.best_fft(h2.to_numpy_u64(a).copy(), d.omega, k, NT))
     bad += not ok
     print("ntt 2^%d %s" % (k, "ok" if ok else "MISMATCH"), flush=True)
+# round 4, late: the first pass's table up to 2^24 points and the inverse's 1/n folded into a scaled copy of it -- against the same transform
+# with the table limited to 2^20 entries (round 3), without the fold, and on the two-level table alone; forward and scaled inverse
+for k in [int(x) for x in os.environ.get("BIG_NTT", "19,21,23,24").split(",") if x]:
+    d = h2.EvaluationDomain.new(2, k)
+    a = h2.gen_scalars_device(70 + k, 1 << k)
+    res = []
+    for full_max, fold, budget in ((0, 1, 4 << 30), (20, 1, 4 << 30), (0, 0, 4 << 30), (0, 1, 0)):
+        L.h2hip_debug_set_ntt_full_max_log_m(ctypes.c_uint32(full_max))
+        L.h2hip_debug_set_ntt_fold_tables(ctypes.c_int(fold))
+        L.h2hip_debug_set_ntt_twiddle_budget(ctypes.c_uint64(budget))
+        x = a.clone(); h2.ntt_device(x, d.omega, k)
+        y = a.clone(); h2.ifft_device(y, d.omega_inv, k, d.ifft_divisor)
+        z = x.clone(); h2.ifft_device(z, d.omega_inv, k, d.ifft_divisor)
+        torch.cuda.synchronize()
+        res.append((x, y, torch.equal(z, a)))
+    L.h2hip_debug_set_ntt_full_max_log_m(ctypes.c_uint32(0))
+    L.h2hip_debug_set_ntt_fold_tables(ctypes.c_int(1))
+    L.h2hip_debug_set_ntt_twiddle_budget(ctypes.c_uint64(4 << 30))
+    ok = all(torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1]) and r[2] for r in res)
+    bad += not ok
+    print("big ntt 2^%d tables / fold / budget %s" % (k, "ok" if ok else "MISMATCH"), flush=True)
+    del res, a
+    torch.cuda.empty_cache()
 # round 3: batched zero-padded coset transforms (coeff_to_extended) -- padding ratios 2, 4, 8, random column counts, the two-pass plan
 # forced from 2^16 points and one workgroup up (first stage pair skipped at ratio >= 4, rows taken by the lanes of their own points)
 # against one column at a time on the three-pass plan
