@@ -41,8 +41,8 @@ from __graft_entry__ import load_pkg  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 MSM_BYTES_PER_PAIR = 96  # 32 B scalar + 64 B affine point, read once
 NTT_BYTES_PER_ELEM = 64  # one 32 B read + one 32 B write per transform
-FIELD_MUL_PER_BUCKET_ADD = 9.2  # XYZZ mixed add: 7 products + 2 squares + one two-product single-reduction form (csrc/ecu.cuh)
-FIELD_MUL_PEAK_G = 179.0  # measured peak of csrc/fieldu.cuh's multiplier on MI355X, G multiplies/s (tools/mul_rate.hip)
+FIELD_MUL_PER_BUCKET_ADD = 9.2  # XYZZ mixed add: 7 products + 2 squares + one two-product single-reduction form (csrc/ecu.h)
+FIELD_MUL_PEAK_G = 179.0  # measured peak of csrc/fieldu.h's multiplier on MI355X, G multiplies/s (tools/mul_rate.hip)
 # Fr multiplications per element of one transform: (log2 n) / 2 butterfly products, plus per pass boundary one to apply the
 # inter-pass twiddle and -- where it is combined from the two-level table instead of read from a per-domain table -- one to combine it;
 # the closing reduction is not a multiplication; each pass's first round forms one product fewer per four points (its twiddle is 1).

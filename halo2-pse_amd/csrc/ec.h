@@ -1,4 +1,4 @@
-// ec.cuh -- BN254 G1 (y^2 = x^3 + 3 over Fq) group law for gfx950 and the library's host side.
+// ec.h -- BN254 G1 (y^2 = x^3 + 3 over Fq) group law for gfx950 and the library's host side.
 //
 // Replaces halo2curves 0.3.1 bn256::{G1Affine, G1} as used by multiexp_serial
 // (halo2_proofs/src/arithmetic.rs:48 double, :62-65 affine+affine / mixed add, :74-77, :98 add,
@@ -8,7 +8,7 @@
 // 8M+2S against 7M+4S for Jacobian and needs no per-add field doublings.  Any correct formulas
 // give the same group element; parity is on the affine value.
 #pragma once
-#include "field.cuh"
+#include "field.h"
 
 namespace h2 {
 

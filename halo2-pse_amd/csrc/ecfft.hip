@@ -6,8 +6,8 @@
 // the reference's iterative form (arithmetic.rs:202-230: bit-reversal, then chunks 2, 4, ... n with
 // twiddles[i * twiddle_chunk]).  Between layers the points are brought back to affine by a batched inversion so that
 // every addition inside the scalar ladder is a mixed addition (9.2 vs 14 multiplications):
-//   ecfft_layer_kernel      t = [w] b by a GLV ladder (glv.cuh: w = w1 + w2 * LAMBDA, 2 + 2-bit joint windows) in the
-//                           unsaturated XYZZ arithmetic of ecu.cuh (the MSM's), the two closing additions in canonical ec.cuh arithmetic; layer 0 applies the
+//   ecfft_layer_kernel      t = [w] b by a GLV ladder (glv.h: w = w1 + w2 * LAMBDA, 2 + 2-bit joint windows) in the
+//                           unsaturated XYZZ arithmetic of ecu.h (the MSM's), the two closing additions in canonical ec.h arithmetic; layer 0 applies the
 //                           bit-reversal on its loads; butterflies with w = 1 skip the ladder (arithmetic.rs:255-260)
 //   ec_normalize_kernel     XYZZ -> affine, Montgomery's trick over 8 points per lane
 //   ec_scale_kernel         [n_inv] p for every point (wave-uniform scalar: no divergence), arithmetic.rs:286-290
@@ -15,9 +15,9 @@
 // affine output is canonical, so it is compared limb for limb.
 #include <string.h>
 
-#include "ecq.cuh"
+#include "ecq.h"
 #include "engine.h"
-#include "glv.cuh"
+#include "glv.h"
 
 namespace h2 {
 
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) ecfft_layer_kernel(EcfftLayer L) {
     L.out[ib] = lo;
 }
 
-// The same ladder with one QUAD of lanes per butterfly (ecq.cuh): up to k = 14 a layer is at most 2^13 butterflies -- a
+// The same ladder with one QUAD of lanes per butterfly (ecq.h): up to k = 14 a layer is at most 2^13 butterflies -- a
 // fraction of the chip's 65 536 SIMD lanes -- and the 130 doublings + 65 additions of a ladder are a pure latency chain.  The four
 // lanes of a quad hold the same point and digits; the 15-entry table is built by every lane for itself (mixed additions).
 __device__ XYZZu ec_mul_affine_glv_q(const Affine& p, const GlvScalar& k, uint32_t role) {

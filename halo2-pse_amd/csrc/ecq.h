@@ -1,4 +1,4 @@
-// ecq.cuh -- BN254 G1 group operations spread over the four lanes of a quad (device only).
+// ecq.h -- BN254 G1 group operations spread over the four lanes of a quad (device only).
 //
 // The tail of a bucket reduction is a chain of a few dozen DEPENDENT group operations on a handful of points; a lone
 // wave issues one instruction per ~4.6 cycles whatever its lane count, so such a chain costs ~3.5 k instructions = 8 us
@@ -8,12 +8,12 @@
 // lanes with quad-permute DPP moves (9 limbs x <= 4 moves).  ~1.3 k instructions per addition instead of ~3.5 k, at
 // four times the lanes -- for phases that have lanes to spare and none for phases that fill the chip.
 //
-// Same formulas, same exceptional-case handling and the same value bounds as ecu.cuh (every coordinate normalised, |x|,
+// Same formulas, same exceptional-case handling and the same value bounds as ecu.h (every coordinate normalised, |x|,
 // |y| < 4.5 p, zz, zzz in (-0.1 p, 1.4 p)); the products are plain fu_mul (no fused two-product reductions), so X3 and Y3
-// are carried through fu_norm where ecu.cuh gets a normalised value from the fused form.  All lanes of a quad take the
+// are carried through fu_norm where ecu.h gets a normalised value from the fused form.  All lanes of a quad take the
 // same branches because they hold the same data.
 #pragma once
-#include "ecu.cuh"
+#include "ecu.h"
 
 namespace h2 {
 

@@ -1,5 +1,5 @@
-// ecu.cuh -- BN254 G1 in XYZZ coordinates over the unsaturated field of fieldu.cuh (I-form
-// values, lazily reduced).  Same group law and the same exceptional-case handling as ec.cuh
+// ecu.h -- BN254 G1 in XYZZ coordinates over the unsaturated field of fieldu.h (I-form
+// values, lazily reduced).  Same group law and the same exceptional-case handling as ec.h
 // (which stays the host-side / reference implementation and the thing this file is fuzzed
 // against in tests/cpp/test_fieldu.cpp); this is what the MSM kernels run.
 //
@@ -11,8 +11,8 @@
 //   U2, S2 in (-0.25, 1.25); |P|, |R| < 5.8; PP, RR < 1.4; |PPP|, |Q| < 1.1; |X3| < 4.5; |Y3| < 2.3.
 // Limb bookkeeping: products always see one operand with |l| < 2^29 and the other < 2^30.
 #pragma once
-#include "ec.cuh"
-#include "fieldu.cuh"
+#include "ec.h"
+#include "fieldu.h"
 
 namespace h2 {
 
@@ -159,7 +159,7 @@ H2_HD void xyzzu_add_affine(XYZZu& acc, const Affine& p, bool negate) {
     xyzzu_add_mixed<QU>(acc, px, py);
 }
 
-// I-form accumulator -> the E-form XYZZ of ec.cuh with canonical coordinates
+// I-form accumulator -> the E-form XYZZ of ec.h with canonical coordinates
 H2_HD XYZZ xyzzu_to_ext(const XYZZu& p) {
     if (xyzzu_is_identity(p)) return xyzz_identity();
     XYZZ o;

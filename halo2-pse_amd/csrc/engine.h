@@ -11,7 +11,7 @@
 #include <vector>
 
 #include "../../include/halo2hip.h"
-#include "ecu.cuh"
+#include "ecu.h"
 
 namespace h2 {
 
@@ -53,7 +53,7 @@ struct TwiddleKey {
 };
 
 struct TwiddleTable {
-    Fu* lo = nullptr;  // omega^i, i < 2^lo_bits                                  (I-form limbs, fieldu.cuh)
+    Fu* lo = nullptr;  // omega^i, i < 2^lo_bits                                  (I-form limbs, fieldu.h)
     Fu* hi = nullptr;  // omega^(i << lo_bits), i < 2^(log_n - lo_bits) (at least 1 entry)
     uint32_t lo_bits = 0;
     // the tile DFT's own twiddles w_R^i, i < R / 2, for R = 2^s (ntt.hip get_stage_twiddles): one table per radix a plan has used on

@@ -8,7 +8,7 @@
 //   evalh_lookup_kernel  one lookup's constraints (:443-518), its compressed-expression graph evaluated in place
 // Advice / instance / lookup polynomials arrive in coefficient form and are taken to the extended coset on the
 // device with the engine's own coeff_to_extended (ntt.hip), as evaluate_h does at :306-323 and :447-457.
-// Arithmetic is the saturated field.cuh (always canonical): this path is bandwidth- and latency-mixed, not the
+// Arithmetic is the saturated field.h (always canonical): this path is bandwidth- and latency-mixed, not the
 // VALU-bound inner loop of the MSM, and canonical values make bit-exactness with the reference immediate.
 #include <dlfcn.h>
 #include <hip/hiprtc.h>
@@ -29,7 +29,7 @@
 
 #include "../../include/halo2hip.h"
 #include "engine.h"
-#include "evalh_dev.cuh"
+#include "evalh_dev.h"
 
 namespace h2 {
 
@@ -42,7 +42,7 @@ namespace h2 {
 // circuit with tens of thousands of calculations still runs with a few dozen slots per lane.  The field operations
 // performed per row are the reference's, operation for operation; only where a value waits between them differs.
 //
-// Arithmetic: the unsaturated 9 x 29-bit multiplier of fieldu.cuh (the MSM's and the NTT's), about half the
+// Arithmetic: the unsaturated 9 x 29-bit multiplier of fieldu.h (the MSM's and the NTT's), about half the
 // instructions of the saturated CIOS.  Inside a kernel every value is I-form (a * 2^261, lazily reduced): a column
 // element (E-form, canonical) becomes I-form for free as the limbs of 32 * x (fu_from_ext), I * I -> I, constants and
 // challenges are converted on the host, and the one value a row writes back goes through the exact reduction
@@ -528,7 +528,7 @@ static Program compile_graph(const h2hip_graph& g) {
 // issue rate because every operation waits for its LDS traffic.  A circuit's program never changes, so it is also emitted as
 // straight-line HIP source -- one statement per operation, slots as local variables (registers, allocated by the compiler),
 // constants as literals, rotations folded into index variables -- and compiled for gfx950 by hiprtc (dlopen'ed; in-memory headers =
-// the library's own field.cuh / fieldu.cuh / evalh_dev.cuh, embedded as text).  The arithmetic per row is the interpreter's,
+// the library's own field.h / fieldu.h / evalh_dev.h, embedded as text).  The arithmetic per row is the interpreter's,
 // operation for operation, so the values are the same limb for limb.  Compilation takes a second or more: it runs on a background
 // thread the first time a program is seen (HALO2_HIP_EVALH_CODEGEN=1, default) while the interpreter serves the calls in between;
 // code objects are cached per process by source hash and, with HALO2_HIP_CACHE_DIR set, on disk.  =2 compiles inline (tests), =0 off.
@@ -641,7 +641,7 @@ static std::string gen_source(const h2hip_graph& g, const Program& P) {
         }
         return t;
     };
-    src += "#include \"evalh_dev.cuh\"\nusing namespace h2;\n"
+    src += "#include \"evalh_dev.h\"\nusing namespace h2;\n"
            "extern \"C\" __global__ void __launch_bounds__(256) evalh_gates_gen(ColsDev c, Fe* __restrict__ values) {\n"
            "    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;\n"
            "    if (idx >= (1u << c.log_size)) return;\n"

@@ -1,9 +1,9 @@
-// evalh_dev.cuh -- what the evaluate_h kernels share with the per-circuit gates kernel that evalh.hip generates and compiles at
-// run time (hiprtc): the columns descriptor, the scalar-load helpers and the I-form field helpers.  Device only.  This file, field.cuh,
-// fieldu.cuh and fieldu_chain.inc are embedded in the library as text (csrc/rtc_headers.inc, made by tools/embed_headers.py) and
+// evalh_dev.h -- what the evaluate_h kernels share with the per-circuit gates kernel that evalh.hip generates and compiles at
+// run time (hiprtc): the columns descriptor, the scalar-load helpers and the I-form field helpers.  Device only.  This file, field.h,
+// fieldu.h and fieldu_chain.inc are embedded in the library as text (csrc/rtc_headers.inc, made by tools/embed_headers.py) and
 // handed to hiprtc as in-memory headers, so the generated kernel is built from the very arithmetic the rest of the engine runs.
 #pragma once
-#include "fieldu.cuh"
+#include "fieldu.h"
 
 namespace h2 {
 

@@ -1,4 +1,4 @@
-// field.cuh -- BN254 base field Fq and scalar field Fr for gfx950 (and the library's host side).
+// field.h -- BN254 base field Fq and scalar field Fr for gfx950 (and the library's host side).
 //
 // Replaces the halo2curves 0.3.1 bn256::{Fq, Fr} arithmetic that halo2_proofs calls on the
 // hot path (reference call sites: halo2_proofs/src/arithmetic.rs:14,48,62-65,74-77,98,197,

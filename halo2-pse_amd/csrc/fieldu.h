@@ -1,15 +1,15 @@
-// fieldu.cuh -- "unsaturated" BN254 field arithmetic for the hot kernels: 9 signed limbs of
+// fieldu.h -- "unsaturated" BN254 field arithmetic for the hot kernels: 9 signed limbs of
 // 29 bits (value = sum l[i] * 2^(29 i)), lazily reduced, Montgomery radix 2^261.
 //
 // Why: on gfx950 every VALU instruction costs about the same (tools/instr_rate.hip), so a modular
 // multiply costs its instruction count.  With 29-bit limbs a whole column of 9 products plus 9
 // reduction products fits a 64-bit accumulator, so v_mad_i64_i32 accumulates with no carry
 // handling at all: ~250 instructions per multiply against ~535 for the saturated 8 x 32 CIOS of
-// field.cuh.  Additions and subtractions are 9 independent 32-bit ops with no carries and no
+// field.h.  Additions and subtractions are 9 independent 32-bit ops with no carries and no
 // conditional subtraction; carries are propagated only where a bound below requires it.
 //
 // Forms (p = modulus, a = the field element):
-//   E-form  value == a * 2^256 (mod p)  -- what the reference stores (field.cuh's Fe, RawBytes)
+//   E-form  value == a * 2^256 (mod p)  -- what the reference stores (field.h's Fe, RawBytes)
 //   I-form  value == a * 2^261 (mod p)  -- Montgomery form for radix 2^261
 //   fu_mul(x, y) = x*y / 2^261 (mod p):  I*I -> I,  E*I -> E  (so NTT data stays in E-form against
 //   I-form twiddles, and E-form constants convert I-form results back for free).
@@ -31,7 +31,7 @@ using make_integer_sequence = __make_integer_seq<integer_sequence, T, N>;
 }  // namespace std
 #endif
 
-#include "field.cuh"
+#include "field.h"
 
 namespace h2 {
 

@@ -1,4 +1,4 @@
-// glv.cuh -- the GLV decomposition of a BN254 scalar: k = k1 + k2 * LAMBDA (mod r) with |k1|, |k2| < 2^128, where
+// glv.h -- the GLV decomposition of a BN254 scalar: k = k1 + k2 * LAMBDA (mod r) with |k1|, |k2| < 2^128, where
 // LAMBDA is the cube root of unity of Fr for which [LAMBDA](x, y) = (BETA * x, y) on G1 (BETA a cube root of unity of Fq).
 // Used by the scalar ladder of g_to_lagrange (ecfft.hip): half the doublings of a 254-bit ladder.
 //
@@ -10,7 +10,7 @@
 //   k1 = k - c1 * A1 - c2 * A2,   k2 = c1 * NB1 - c2 * B2
 // The identity holds for any integers c1, c2; the floors only cost a bit of size (measured maximum: 127 bits).
 #pragma once
-#include "field.cuh"
+#include "field.h"
 
 namespace h2 {
 

@@ -1,12 +1,12 @@
 // host64.h -- host-only Fq / G1 arithmetic on 4 x 64-bit limbs (unsigned __int128), same byte layout as
-// field.cuh's Fe.  Used for the few hundred group operations that finish an MSM on the CPU: the Horner
-// over window sums (arithmetic.rs:46-49) and the fold of partials (arithmetic.rs:153).  field.cuh's
+// field.h's Fe.  Used for the few hundred group operations that finish an MSM on the CPU: the Horner
+// over window sums (arithmetic.rs:46-49) and the fold of partials (arithmetic.rs:153).  field.h's
 // portable 8 x 32 code is ~4x slower on x86-64 and made that tail ~0.2 ms per MSM.
 #pragma once
 #include <stdint.h>
 #include <string.h>
 
-#include "ec.cuh"
+#include "ec.h"
 
 namespace h2 {
 namespace h64 {

@@ -46,7 +46,7 @@
 #include <thread>
 #include <vector>
 
-#include "ecq.cuh"
+#include "ecq.h"
 #include "engine.h"
 #include "host64.h"
 
@@ -650,7 +650,7 @@ __device__ __forceinline__ XYZZu block_tree_sum(XYZZu v, XYZZu* sh) {
     return sh[0];
 }
 
-// the same sum with one QUAD of lanes per addition (ecq.cuh): 64 quads, 2 + 1 + ... + 1 = 9 dependent quad additions instead of 8
+// the same sum with one QUAD of lanes per addition (ecq.h): 64 quads, 2 + 1 + ... + 1 = 9 dependent quad additions instead of 8
 // lane additions at twice their latency (an over-full bucket's sum is nothing but such trees: 15 levels for 26 k entries)
 __device__ __forceinline__ XYZZu block_tree_sum_q(const XYZZu& v, XYZZu* sh) {
     sh[threadIdx.x] = v;
@@ -786,7 +786,7 @@ __global__ void __launch_bounds__(256) msm_rowcol_kernel(RowColArgs args) {
 // The same sums for the first pass over a single bucket set (the fixed-base form's 2^19..2^21 buckets), where the work is
 // throughput -- 2 general additions per bucket -- and the lane kernel above loses a third of it to five tree levels on mostly
 // idle lanes at one wave per SIMD: here every lane chains only a few terms (four waves per SIMD reach the issue rate a lone wave
-// cannot), and the 2^g_log partials of a sum are then added pairwise by QUADS of lanes (ecq.cuh: a third of a lane's latency per
+// cannot), and the 2^g_log partials of a sum are then added pairwise by QUADS of lanes (ecq.h: a third of a lane's latency per
 // addition), 64 quads per workgroup, level by level through LDS.
 template <class F>
 __global__ void __launch_bounds__(256) msm_rowcol_qtree_kernel(RowColArgs args) {
@@ -863,7 +863,7 @@ __global__ void __launch_bounds__(256) msm_final_kernel(FinalArgs args, XYZZ* __
     if (threadIdx.x == 0) set_sums[set] = xyzzu_to_ext(r);  // canonical E-form
 }
 
-// ---- the same two kernels with one QUAD of lanes per group operation (ecq.cuh), for runs with few bucket sets, whose
+// ---- the same two kernels with one QUAD of lanes per group operation (ecq.h), for runs with few bucket sets, whose
 // ---- reduction tail is a latency chain on a handful of waves.  Workgroups are single waves so that the chains spread
 // ---- over the chip's SIMDs instead of sharing one CU's issue slots.
 
@@ -1494,7 +1494,7 @@ static int msm_stage_c(Ctx* c, const MsmLayout& L, char* base, XYZZ* h_sums, hip
     XYZZ* sums = direct ? h_sums : (XYZZ*)(base + L.o_sums);
     const uint32_t ns = L.n_sets, cb = L.p.cb;
     // few sets: the second row/column pass and the final scaling are latency chains on a handful of waves -- one quad of
-    // lanes per group operation (ecq.cuh).  Many sets (fused batches of the plain form) fill the chip: one lane each.
+    // lanes per group operation (ecq.h).  Many sets (fused batches of the plain form) fill the chip: one lane each.
     const bool quad = g_quad_tail && ns <= 64;
     int t4 = c->timer_begin("msm_reduce", s);
     FinalArgs fa;

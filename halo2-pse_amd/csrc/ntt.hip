@@ -30,7 +30,7 @@
 #include <vector>
 
 #include "engine.h"
-#include "fieldu.cuh"
+#include "fieldu.h"
 
 namespace h2 {
 
@@ -68,7 +68,7 @@ __device__ __forceinline__ Fe* ntt_dst(const NttPass& p) { return p.dsts ? p.dst
 #endif
 
 // Arithmetic: data stays in the reference's E-form (value == a * 2^256 mod r) as lazily reduced
-// 9 x 29-bit limbs (fieldu.cuh); twiddles and scale constants are I-form, so every
+// 9 x 29-bit limbs (fieldu.h); twiddles and scale constants are I-form, so every
 // fu_mul(data, twiddle) is again E-form and the last multiply of a pass doubles as the exact
 // reduction back to canonical limbs (fu_mul_canon).
 

@@ -23,7 +23,7 @@
 #include <vector>
 
 #include "../../include/halo2hip.h"
-#include "../csrc/ec.cuh"  // host-side Fr / Fq / G1 arithmetic for domain constants and SRS checks (no HIP needed)
+#include "../csrc/ec.h"  // host-side Fr / Fq / G1 arithmetic for domain constants and SRS checks (no HIP needed)
 
 namespace halo2_proofs {
 

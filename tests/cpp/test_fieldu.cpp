@@ -1,5 +1,5 @@
-// Host-side fuzz of csrc/fieldu.cuh + csrc/ecu.cuh (the unsaturated arithmetic the kernels run)
-// against csrc/field.cuh + csrc/ec.cuh (the saturated arithmetic, itself checked against the oracle
+// Host-side fuzz of csrc/fieldu.h + csrc/ecu.h (the unsaturated arithmetic the kernels run)
+// against csrc/field.h + csrc/ec.h (the saturated arithmetic, itself checked against the oracle
 // by tests/test_abi.py).  Built with -DH2_FU_CHECK so every fu_mul / fu_add asserts its limb bounds.
 // No GPU needed: the same H2_HD source compiles for the host.
 #include <cstdio>
@@ -8,8 +8,8 @@
 
 #include <cstring>
 
-#include "../../halo2-pse_amd/csrc/ecu.cuh"
-#include "../../halo2-pse_amd/csrc/glv.cuh"
+#include "../../halo2-pse_amd/csrc/ecu.h"
+#include "../../halo2-pse_amd/csrc/glv.h"
 
 using namespace h2;
 
@@ -259,7 +259,7 @@ static void test_ec() {
     printf("ec fuzz done, failures so far %d\n", failures);
 }
 
-// glv.cuh: k == k1 + k2 * LAMBDA (mod r), |k1|, |k2| < 2^128, and [LAMBDA](x, y) == (BETA * x, y) on the curve
+// glv.h: k == k1 + k2 * LAMBDA (mod r), |k1|, |k2| < 2^128, and [LAMBDA](x, y) == (BETA * x, y) on the curve
 static Fe fe_from_limbs5(const uint32_t v[5]) {
     Fe c = fe_zero<FrP>();
     for (int i = 0; i < 5; i++) c.l[i] = v[i];

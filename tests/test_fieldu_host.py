@@ -1,6 +1,6 @@
 """CPU: the unsaturated (9 x 29-bit, lazily reduced) field / curve arithmetic the kernels run
-(csrc/fieldu.cuh, csrc/ecu.cuh) fuzzed on the host against the saturated arithmetic
-(csrc/field.cuh, csrc/ec.cuh), with every limb bound asserted (-DH2_FU_CHECK)."""
+(csrc/fieldu.h, csrc/ecu.h) fuzzed on the host against the saturated arithmetic
+(csrc/field.h, csrc/ec.h), with every limb bound asserted (-DH2_FU_CHECK)."""
 import os
 import subprocess
 

@@ -1,7 +1,7 @@
 """CPU tests of the host-side code around the C ABI (no GPU, no compute calls):
   * EvaluationDomain::new in both host mirrors (Python: halo2-pse_amd/__init__.py, C++: host/halo2hip.hpp) against the
     golden domain constants -- neither takes them from the oracle;
-  * the C++ host code (tests/cpp/*.cpp with host/*.hpp and csrc/{field,fieldu,ec,ecu,glv}.cuh compiled for the host)
+  * the C++ host code (tests/cpp/*.cpp with host/*.hpp and csrc/{field,fieldu,ec,ecu,glv}.h compiled for the host)
     under AddressSanitizer + UndefinedBehaviorSanitizer;
   * bench.py --gpus N started bare spawns its N ranks itself and hands their exit code through."""
 import os

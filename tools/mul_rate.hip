@@ -1,7 +1,7 @@
 // tools/mul_rate.hip -- throughput/latency of fu_mul variants on gfx950 at 1, 2, 4 waves per SIMD.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-#include "../halo2-pse_amd/csrc/fieldu.cuh"
+#include "../halo2-pse_amd/csrc/fieldu.h"
 using namespace h2;
 
 // variant 1: two accumulators per column (a*b chain and m*p chain)

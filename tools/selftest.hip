@@ -1,9 +1,9 @@
-// tools/selftest.hip -- device-vs-host self check of field.cuh / ec.cuh on the GPU box: the same
+// tools/selftest.hip -- device-vs-host self check of field.h / ec.h on the GPU box: the same
 // H2_HD source runs on the host (validated against the oracle by tests/test_abi.py) and in a kernel.
 #include <stdio.h>
 #include <string.h>
 #include <vector>
-#include "../halo2-pse_amd/csrc/ec.cuh"
+#include "../halo2-pse_amd/csrc/ec.h"
 using namespace h2;
 
 struct Out { Fe mul, add, sub, sqr, pow, inv, canon; };
