@@ -543,6 +543,9 @@ __device__ __noinline__ void msm_heavy_role(const Affine* __restrict__ bases, co
 // sub + 2S, ... into parts[bucket * S + sub].  A run with few buckets (a lone MSM of <= 2^17 pairs over a window table
 // has 2^16) would otherwise be one wave per SIMD walking ~30 dependent additions per lane.
 // `bases` is the caller's point array (plain form) or the window table (fixed-base form).
+#ifdef H2_ACCUM_TIMELINE  // measurement builds only (tools/accum_timeline.py): entry / exit time, first lane's bucket size and HW_ID of every accumulate wave
+__device__ unsigned long long g_accum_tl[6 * 16384];
+#endif
 __global__ void __launch_bounds__(256, 4) msm_accum_kernel(const Affine* __restrict__ bases, const uint32_t* __restrict__ vals,
                                                         const uint32_t* __restrict__ start, const uint32_t* __restrict__ counts,
                                                         const uint32_t* __restrict__ perm, uint32_t n_buckets, uint32_t split_log, uint32_t heavy_t,
@@ -560,6 +563,10 @@ __global__ void __launch_bounds__(256, 4) msm_accum_kernel(const Affine* __restr
     const uint32_t S = 1u << split_log, sub = t & (S - 1);
     const uint32_t b = perm[t >> split_log];  // buckets in descending size order
     uint32_t s = start[b], e = s + counts[b];
+#ifdef H2_ACCUM_TIMELINE
+    const unsigned long long tl0 = wall_clock64(), tc0 = clock64();  // constant 100 MHz / shader clock
+    const uint32_t tl_cnt = e - s;
+#endif
     XYZZu acc = xyzzu_identity();
     XYZZu* const mine = parts + (((size_t)b << split_log) + sub);
     bool store = !cont;  // cont: the parts hold the sums of the earlier chunks of a streamed MSM; a lane with nothing to add leaves its part alone
@@ -610,7 +617,27 @@ __global__ void __launch_bounds__(256, 4) msm_accum_kernel(const Affine* __restr
         xyzzu_add_affine<FqUA>(acc, p, (v >> 31) != 0);
     }
     if (store) *mine = acc;
+#ifdef H2_ACCUM_TIMELINE
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t w = (blockIdx.x - hgrid) * 4 + (threadIdx.x >> 6);
+        if (w < 16384) {
+            g_accum_tl[6 * w] = tl0;
+            g_accum_tl[6 * w + 1] = wall_clock64();
+            g_accum_tl[6 * w + 2] = tl_cnt;
+            g_accum_tl[6 * w + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+            g_accum_tl[6 * w + 4] = tc0;
+            g_accum_tl[6 * w + 5] = clock64();
+        }
+    }
+#endif
 }
+#ifdef H2_ACCUM_TIMELINE
+}  // namespace h2
+extern "C" int h2hip_debug_accum_timeline(unsigned long long* out, size_t n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(h2::g_accum_tl), n * sizeof(unsigned long long));
+}
+namespace h2 {
+#endif
 
 // B': bucket = sum of its 2^split_log parts (msm_heavy_final has added an over-full bucket's sum to its first part by then).
 // Half as many lanes as parts: every lane adds one pair, the pair sums of a bucket then meet in a tree through LDS -- log2(S)
