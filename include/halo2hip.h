@@ -39,7 +39,8 @@
  * HALO2_HIP_LAZY_PIN=k (default 0 = off) lets the library pin a host bases array by itself once a
  * host-pointer MSM has seen it k times (see h2hip_bases_pin); HALO2_HIP_EVALH_CODEGEN=0|1|2 the per-circuit custom-gates kernel of
  * h2hip_evaluate_h_bn254 (0: byte-code interpreter only; 1, default: generated and compiled by hiprtc on a background thread, the interpreter
- * serves until the code object is ready; 2: compiled inline) and HALO2_HIP_CACHE_DIR a directory that keeps those code objects across processes.
+ * serves until the code object is ready; 2: compiled inline) and HALO2_HIP_CACHE_DIR a directory that keeps those code objects across processes
+ * (files there are loaded as GPU code, keyed by a hash of their source: the directory must be writable by the prover's user only).
  */
 #ifndef HALO2HIP_H
 #define HALO2HIP_H
