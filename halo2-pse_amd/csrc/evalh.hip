@@ -246,14 +246,13 @@ __global__ void __launch_bounds__(256) evalh_perm_kernel(PermDev p, ColsDev c, F
         const uint32_t j0 = s * p.chunk_len, j1 = j0 + p.chunk_len < p.n_cols ? j0 + p.chunk_len : p.n_cols;
         const Fe* zs = ld_const_col(p.z, s);
         Fu left = ld_i(zs[r_next]), right = ld_i(zs[idx]);  // [32]
-        for (uint32_t j = j0; j < j1; j++) {
-            const Fu term = addn(addn(ld_i(ld_const_col(p.cols, j)[idx]), mul_i(c.beta, ld_i(ld_const_col(p.cosets, j)[idx]))), c.gamma);  // [32 + 1.2 + 1 = 34.2]
-            left = mul_i(left, term);                                                                          // [32 * 34.2 / 169 + 1 = 7.5], then smaller
-        }
-        for (uint32_t j = j0; j < j1; j++) {
-            const Fu term = addn(addn(ld_i(ld_const_col(p.cols, j)[idx]), current_delta), c.gamma);  // [35]
-            right = mul_i(right, term);                                                // [7.7]
-            current_delta = mul_i(current_delta, p.delta);                             // [1.1]
+        for (uint32_t j = j0; j < j1; j++) {  // both products in one walk over the set's columns: a column's value is read once
+            const Fu col = ld_i(ld_const_col(p.cols, j)[idx]);
+            const Fu lterm = addn(addn(col, mul_i(c.beta, ld_i(ld_const_col(p.cosets, j)[idx]))), c.gamma);  // [32 + 1.2 + 1 = 34.2]
+            left = mul_i(left, lterm);                                                                         // [32 * 34.2 / 169 + 1 = 7.5], then smaller
+            const Fu rterm = addn(addn(col, current_delta), c.gamma);                                          // [35]
+            right = mul_i(right, rterm);                                                                       // [7.7]
+            current_delta = mul_i(current_delta, p.delta);                                                     // [1.1]
         }
         v = addn(mul_i(v, c.y), mul_i(subn(left, right), ld_i(p.l_active[idx])));     // [1.1] + [64 * 32 / 169 + 1 = 13.2] = [14.3]
     }
