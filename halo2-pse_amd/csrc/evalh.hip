@@ -259,40 +259,15 @@ __global__ void __launch_bounds__(256) evalh_perm_kernel(PermDev p, ColsDev c, F
     values[idx] = out_e(v);  // [< 15]
 }
 
-struct LookupDev {
-    const Fe *product, *pin, *ptab;  // extended cosets of product / permuted input / permuted table
-    const Fe *l0, *l_last, *l_active;
-};
-
 template <int MAXI>
 __global__ void __launch_bounds__(256) evalh_lookup_kernel(ProgDev g, LookupDev l, ColsDev c, Fe* values, Fu* gws, uint32_t lanes) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= lanes) return;
     Slots<MAXI> slots(gws + tid, lanes);
-    const Fu one = fu_one_i<UF>();
     for (uint64_t row = tid; row < (1ull << c.log_size); row += lanes) {
         const uint32_t idx = (uint32_t)row;
         const Fu table_value = prog_eval(g, c, idx, fu_zero(), slots);  // :466-480   [< 32]
-        const uint32_t r_next = rot_idx(idx, 1, c.rot_scale, c.log_size), r_prev = rot_idx(idx, -1, c.rot_scale, c.log_size);
-        const Fu z = ld_i(l.product[idx]), a_ = ld_i(l.pin[idx]), s_ = ld_i(l.ptab[idx]);  // [32]
-        const Fu l0 = ld_i(l.l0[idx]), l_active = ld_i(l.l_active[idx]);                  // [32]
-        const Fu a_minus_s = subn(a_, s_);                                                // [64]
-        Fu v = ld_i(values[idx]);                                                         // [32]
-        // l_0(X) * (1 - z(X)) = 0
-        v = addn(mul_i(v, c.y), mul_i(subn(one, z), l0));                                             // [1.2 + 7.3 = 8.5]
-        // l_last(X) * (z(X)^2 - z(X)) = 0
-        v = addn(mul_i(v, c.y), mul_i(subn(fu_sqr<UF>(z), z), ld_i(l.l_last[idx])));                  // [1.1 + 8.4 = 9.5]
-        // (1 - (l_last + l_blind)) * (z(wX)(a' + beta)(s' + gamma) - z(X) * table_value) = 0
-        {
-            const Fu lhs = mul_i(mul_i(ld_i(l.product[r_next]), addn(a_, c.beta)), addn(s_, c.gamma));  // [32 * 33 / 169 + 1 = 7.3] -> [7.3 * 33 / 169 + 1 = 2.5]
-            const Fu rhs = mul_i(z, table_value);                                                       // [32 * 32 / 169 + 1 = 7.1]
-            v = addn(mul_i(v, c.y), mul_i(subn(lhs, rhs), l_active));                                   // [1.1] + [9.6 * 32 / 169 + 1 = 2.9] = [4]
-        }
-        // l_0(X) * (a'(X) - s'(X)) = 0
-        v = addn(mul_i(v, c.y), mul_i(a_minus_s, l0));                                                  // [1.1] + [64 * 32 / 169 + 1 = 13.2] = [14.3]
-        // (1 - (l_last + l_blind)) * (a' - s') * (a'(X) - a'(w^-1 X)) = 0
-        v = addn(mul_i(v, c.y), mul_i(mul_i(a_minus_s, subn(a_, ld_i(l.pin[r_prev]))), l_active));      // [1.1] + [(64 * 64 / 169 + 1 = 25.3) * 32 / 169 + 1 = 5.8] = [6.9]
-        values[idx] = out_e(v);
+        lookup_row(l, c, idx, table_value, values);
     }
 }
 
@@ -592,7 +567,9 @@ static bool hiprtc_load() {  // under g_rtc_mu
 // the program as HIP source.  Operands: constants are literals (I-form limbs), slots are locals, a column operand is a load at the
 // row index of its rotation (one index variable per distinct rotation), challenges and beta / gamma / theta / y come with the launch.
 static bool g_evalh_gen_barriers = true;
-static std::string gen_source(const h2hip_graph& g, const Program& P) {
+// lookup: the program is a lookup argument's compressed table expression (evaluated with PreviousValue = 0, :466-480) and the kernel ends
+// with that argument's five constraints (lookup_row, evalh_dev.h) instead of storing the program's result.
+static std::string gen_source(const h2hip_graph& g, const Program& P, bool lookup = false) {
     const bool sched_barriers = g_evalh_gen_barriers;
     std::string src;
     src.reserve(64 * P.ops.size() + 4096);
@@ -640,13 +617,15 @@ static std::string gen_source(const h2hip_graph& g, const Program& P) {
         }
         return t;
     };
-    src += "#include \"evalh_dev.h\"\nusing namespace h2;\n"
-           "extern \"C\" __global__ void __launch_bounds__(256) evalh_gates_gen(ColsDev c, Fe* __restrict__ values) {\n"
-           "    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;\n"
-           "    if (idx >= (1u << c.log_size)) return;\n"
-           "    const Fe prev_e = values[idx];\n"
-           "    const Fu prev = ld_i(prev_e);\n"
-           "    (void)prev;\n";
+    src += "#include \"evalh_dev.h\"\nusing namespace h2;\n";
+    src += lookup ? "extern \"C\" __global__ void __launch_bounds__(256) evalh_lookup_gen(ColsDev c, LookupDev l, Fe* values) {\n"
+                  : "extern \"C\" __global__ void __launch_bounds__(256) evalh_gates_gen(ColsDev c, Fe* __restrict__ values) {\n";
+    src += "    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;\n"
+           "    if (idx >= (1u << c.log_size)) return;\n";
+    src += lookup ? "    const Fu prev = fu_zero();\n"
+                  : "    const Fe prev_e = values[idx];\n"
+                    "    const Fu prev = ld_i(prev_e);\n";
+    src += "    (void)prev;\n";
     for (uint32_t i = 0; i < g.n_constants; i++)
         if (use_const[i]) {
             const Fu k = to_i(load_fe(g.constants + 4 * (size_t)i));
@@ -744,6 +723,10 @@ static std::string gen_source(const h2hip_graph& g, const Program& P) {
         // scheduler and the register allocator minutes and buys nothing -- a field multiplication already fills the pipeline
         if (sched_barriers) src += "    __builtin_amdgcn_sched_barrier(0);\n";
     }
+    if (lookup) {
+        add("    lookup_row(l, c, idx, %s, values);\n}\n", operand(P.result).c_str());
+        return src;
+    }
     switch (P.result.kind) {  // prog_result_e
         case H2HIP_VS_FIXED: case H2HIP_VS_ADVICE: case H2HIP_VS_INSTANCE:
             add("    values[idx] = %c%u[r%u];\n", col_name[P.result.kind - H2HIP_VS_FIXED], P.result.a, P.result.b);
@@ -816,6 +799,10 @@ static void rtc_compile(std::shared_ptr<RtcEntry> e, std::string src, uint64_t k
         }
     }
     if (!ok) {
+        // one compilation at a time: a circuit brings a gates kernel and one kernel per lookup, each on its own background thread, and
+        // nothing here relies on the run-time compiler being re-entrant
+        static std::mutex compile_mu;
+        std::lock_guard<std::mutex> one(compile_mu);
         hiprtcProgram prog = nullptr;
         hiprtcResult r = g_hiprtc.Create(&prog, src.c_str(), "evalh_gates_gen.hip", H2_RTC_N_HEADERS, H2_RTC_HEADER_TEXT, H2_RTC_HEADER_NAMES);
         if (r == HIPRTC_SUCCESS) {
@@ -907,9 +894,9 @@ void evalh_modules_free(Ctx* c) {
 
 // the generated kernel for this program on this device, or nullptr: not wanted, not compiled yet (the interpreter serves this
 // call), or not compilable (it serves every call)
-static hipFunction_t gates_kernel_for(Ctx* c, const h2hip_graph& g, const Program& P) {
-    if (g_evalh_codegen <= 0 || P.ops.empty() || P.ops.size() > g_evalh_codegen_max_ops || P.n_slots > EVALH_CODEGEN_MAX_SLOTS) return nullptr;
-    std::string src = gen_source(g, P);
+static hipFunction_t gates_kernel_for(Ctx* c, const h2hip_graph& g, const Program& P, bool lookup = false) {
+    if (g_evalh_codegen <= 0 || (P.ops.empty() && !lookup) || P.ops.size() > g_evalh_codegen_max_ops || P.n_slots > EVALH_CODEGEN_MAX_SLOTS) return nullptr;
+    std::string src = gen_source(g, P, lookup);
     const uint64_t key = fnv1a64(src);
     auto hit = c->evalh_mods.find(key);
     if (hit != c->evalh_mods.end()) return (hipFunction_t)hit->second.second;
@@ -944,7 +931,7 @@ static hipFunction_t gates_kernel_for(Ctx* c, const h2hip_graph& g, const Progra
     if (e->state != 1) return nullptr;
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
-    if (hipModuleLoadData(&mod, e->code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, "evalh_gates_gen") != hipSuccess) {
+    if (hipModuleLoadData(&mod, e->code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, lookup ? "evalh_lookup_gen" : "evalh_gates_gen") != hipSuccess) {
         (void)hipGetLastError();
         if (mod) (void)hipModuleUnload(mod);
         c->evalh_mods[key] = {nullptr, nullptr};  // do not try again on this device
@@ -1351,6 +1338,14 @@ int evaluate_h_host(Ctx* c, const h2hip_evalh_desc* d, uint64_t* values, bool de
         const ProgDev& lg = lgs[i];
         LookupDev ld = {lbuf[3 * gi], lbuf[3 * gi + 1], lbuf[3 * gi + 2], l0, l_last, l_active};
         const SlotPlan& lp = lookup_plans[i];
+        if (hipFunction_t lgen = gates_kernel_for(c, d->lookup_graphs[i], lookup_progs[i], true)) {  // generated for this circuit, as the gates kernel is
+            Fe* vals = d_values;
+            void* args[] = {(void*)&cols, (void*)&ld, (void*)&vals};
+            H2_CHECK(hipModuleLaunchKernel(lgen, (uint32_t)((size + 255) / 256), 1, 1, 256, 1, 1, 0, s, args, nullptr));
+            g_rtc_stats.launches++;
+            continue;
+        }
+        g_rtc_stats.interpreted++;
         const dim3 g(lp.lanes / 256);
         switch (lp.tier) {
             case 4: hipLaunchKernelGGL(evalh_lookup_kernel<4>, g, block, 4 * 9 * 256 * 4, s, lg, ld, cols, d_values, gws, lp.lanes); break;

@@ -48,4 +48,34 @@ __device__ __forceinline__ uint32_t rot_idx(uint32_t idx, int32_t rot, int32_t r
     return (uint32_t)((int32_t)idx + rot * rot_scale) & ((1u << log_size) - 1);
 }
 
+// One lookup argument's share of a row (evaluation.rs:443-518), given the compressed table expression of that row: shared by the
+// interpreter's lookup kernel and the one generated per circuit.  Magnitudes in units of r are given in brackets.
+struct LookupDev {
+    const Fe *product, *pin, *ptab;  // extended cosets of product / permuted input / permuted table
+    const Fe *l0, *l_last, *l_active;
+};
+__device__ __forceinline__ void lookup_row(const LookupDev& l, const ColsDev& c, uint32_t idx, const Fu& table_value, Fe* values) {
+    const Fu one = fu_one_i<UF>();
+    const uint32_t r_next = rot_idx(idx, 1, c.rot_scale, c.log_size), r_prev = rot_idx(idx, -1, c.rot_scale, c.log_size);
+    const Fu z = ld_i(l.product[idx]), a_ = ld_i(l.pin[idx]), s_ = ld_i(l.ptab[idx]);  // [32]
+    const Fu l0 = ld_i(l.l0[idx]), l_active = ld_i(l.l_active[idx]);                  // [32]
+    const Fu a_minus_s = subn(a_, s_);                                                // [64]
+    Fu v = ld_i(values[idx]);                                                         // [32]
+    // l_0(X) * (1 - z(X)) = 0
+    v = addn(mul_i(v, c.y), mul_i(subn(one, z), l0));                                             // [1.2 + 7.3 = 8.5]
+    // l_last(X) * (z(X)^2 - z(X)) = 0
+    v = addn(mul_i(v, c.y), mul_i(subn(fu_sqr<UF>(z), z), ld_i(l.l_last[idx])));                  // [1.1 + 8.4 = 9.5]
+    // (1 - (l_last + l_blind)) * (z(wX)(a' + beta)(s' + gamma) - z(X) * table_value) = 0
+    {
+        const Fu lhs = mul_i(mul_i(ld_i(l.product[r_next]), addn(a_, c.beta)), addn(s_, c.gamma));  // [32 * 33 / 169 + 1 = 7.3] -> [7.3 * 33 / 169 + 1 = 2.5]
+        const Fu rhs = mul_i(z, table_value);                                                       // [32 * 32 / 169 + 1 = 7.1]
+        v = addn(mul_i(v, c.y), mul_i(subn(lhs, rhs), l_active));                                   // [1.1] + [9.6 * 32 / 169 + 1 = 2.9] = [4]
+    }
+    // l_0(X) * (a'(X) - s'(X)) = 0
+    v = addn(mul_i(v, c.y), mul_i(a_minus_s, l0));                                                  // [1.1] + [64 * 32 / 169 + 1 = 13.2] = [14.3]
+    // (1 - (l_last + l_blind)) * (a' - s') * (a'(X) - a'(w^-1 X)) = 0
+    v = addn(mul_i(v, c.y), mul_i(mul_i(a_minus_s, subn(a_, ld_i(l.pin[r_prev]))), l_active));      // [1.1] + [(64 * 64 / 169 + 1 = 25.3) * 32 / 169 + 1 = 5.8] = [6.9]
+    values[idx] = out_e(v);
+}
+
 }  // namespace h2

@@ -604,8 +604,10 @@ def test_generated_kernel_disk_cache_across_processes(tmp_path):
         outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:]))
     first, second = outs
     assert first["match"] and second["match"]
-    assert first["disk_hits"] == 0 and first["compiled"] == 1 and first["launches"] >= 1 and len(first["files"]) == 1 and first["files"][0].endswith("_gfx950.co")
-    assert second["disk_hits"] == 1 and second["launches"] >= 1 and second["files"] == first["files"]
+    # one code object for the custom gates and one per lookup argument whose table expression is distinct
+    assert first["disk_hits"] == 0 and first["compiled"] >= 1 and first["launches"] >= 1 and len(first["files"]) == first["compiled"]
+    assert all(f.endswith("_gfx950.co") for f in first["files"])
+    assert second["disk_hits"] == first["compiled"] and second["launches"] >= 1 and second["files"] == first["files"]
 
 
 @pytest.mark.gpu
