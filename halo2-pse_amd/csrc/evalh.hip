@@ -853,7 +853,8 @@ int evalh_debug_codegen_source(const h2hip_graph* g, char* buf, size_t cap, size
     any.n_fixed = any.n_advice = any.n_instance = any.n_challenges = 0xffffffffu;
     if (graph_validate(*g, any, "given")) return 1;
     const Program P = compile_graph(*g);
-    const std::string src = gen_source(*g, P);
+    const std::string src = gen_source(*g, P, (compile & 2) != 0);  // bit 1: the graph as a lookup's table expression (evalh_lookup_gen)
+    compile &= 1;
     *len = src.size();
     if (buf && cap) {
         const size_t m = src.size() < cap - 1 ? src.size() : cap - 1;

@@ -77,8 +77,9 @@ int h2hip_debug_evalh_program_muls(const h2hip_graph* g, uint32_t* n_mul);
  * HALO2_HIP_EVALH_CODEGEN), 2 compiled inline; + 16: without the fusion of two products into one reduction; max_ops: programs with more operations (or more than 48
  * values alive at once) stay with the interpreter (0 = default 1200) */
 int h2hip_debug_set_evalh_codegen(int mode, uint32_t max_ops);
-/* the HIP source a graph's program is emitted as (buf may be NULL: *len alone), and with compile != 0 what hiprtc makes of it for gfx950
- * (seconds, bytes of code object); needs no GPU.  Returns 0, 1 (malformed graph) or 2 (hiprtc missing / rejected the source). */
+/* the HIP source a graph's program is emitted as (buf may be NULL: *len alone), and with bit 0 of `compile` set what hiprtc makes of it for
+ * gfx950 (seconds, bytes of code object); bit 1: the graph as a lookup argument's table expression (evalh_lookup_gen) instead of the custom
+ * gates (evalh_gates_gen); needs no GPU.  Returns 0, 1 (malformed graph) or 2 (hiprtc missing / rejected the source). */
 int h2hip_debug_evalh_codegen_source(const h2hip_graph* g, char* buf, size_t cap, size_t* len, int compile, double* seconds, size_t* code_bytes);
 /* out: programs compiled, compilations failed, launches of a generated kernel, launches of the interpreter, disk-cache hits */
 int h2hip_debug_evalh_codegen_stats(uint64_t out[5]);

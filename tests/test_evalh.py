@@ -493,7 +493,7 @@ def _random_graph(rng, n_calcs, n_adv=5, n_fix=6):
     return g
 
 
-def _codegen(h2, graph_dict, compile_it=True):
+def _codegen(h2, graph_dict, compile_it=True, lookup=False):
     """(source, seconds, code bytes) of the per-circuit gates kernel for a flattened graph: host-only, hiprtc cross-compiles gfx950 without a GPU"""
     from evalh_util import DescHolder as DH
     holder = DH.__new__(DH)
@@ -501,10 +501,10 @@ def _codegen(h2, graph_dict, compile_it=True):
     G = holder._graph(graph_dict)
     L = h2.lib()
     n = ctypes.c_size_t()
-    assert L.h2hip_debug_evalh_codegen_source(ctypes.byref(G), None, ctypes.c_size_t(0), ctypes.byref(n), ctypes.c_int(0), None, None) == 0
+    assert L.h2hip_debug_evalh_codegen_source(ctypes.byref(G), None, ctypes.c_size_t(0), ctypes.byref(n), ctypes.c_int(2 if lookup else 0), None, None) == 0
     buf = ctypes.create_string_buffer(n.value + 1)
     secs, size = ctypes.c_double(), ctypes.c_size_t()
-    rc = L.h2hip_debug_evalh_codegen_source(ctypes.byref(G), buf, ctypes.c_size_t(n.value + 1), ctypes.byref(n), ctypes.c_int(1 if compile_it else 0),
+    rc = L.h2hip_debug_evalh_codegen_source(ctypes.byref(G), buf, ctypes.c_size_t(n.value + 1), ctypes.byref(n), ctypes.c_int((1 if compile_it else 0) | (2 if lookup else 0)),
                                             ctypes.byref(secs), ctypes.byref(size))
     assert rc == 0, L.h2hip_last_error().decode()
     return buf.value.decode(), secs.value, size.value
@@ -530,6 +530,10 @@ def test_generated_gates_kernel_compiles_for_gfx950(h2, oracle, evalh_golden):
     for _ in range(4):
         _, _, size = _codegen(h2, flatten_graph(_random_graph(rng, int(rng.integers(5, 90)))))
         assert size > 1000
+    # the lookup arguments' kernels: the compressed table expression, then the argument's five constraints (lookup_row)
+    for lk in list(case["lookups"]) + list(big["lookups"][:1]):
+        src, _, size = _codegen(h2, lk[0], lookup=True)
+        assert "evalh_lookup_gen" in src and "lookup_row(l, c, idx," in src and size > 1000
 
 
 def test_compile_survives_random_graphs(h2):
