@@ -627,8 +627,11 @@ static int get_full_twiddles(Ctx* c, const Fe& omega, const NttPass& p, bool two
         hipLaunchKernelGGL(full_twiddle_build_kernel, grid, dim3(256), 0, s, q, d);
     else
         hipLaunchKernelGGL(pass_twiddle_build_kernel, grid, dim3(256), 0, s, q, d);
-    H2_CHECK(hipGetLastError());
-    H2_CHECK(hipStreamSynchronize(s));
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        (void)hipFree(d);
+        set_error("ntt: building an inter-pass twiddle table failed");
+        return 2;
+    }
     t.full[free_slot] = d;
     t.full_tag[free_slot] = tag;
     if (scale) t.full_scale[free_slot] = *scale;
