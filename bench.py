@@ -74,7 +74,10 @@ def pmc_traffic(workload):
         return None
 
 
-def pmc_pass(child_flags, counters, names, timeout=100):
+_PMC_BROKEN = [False]  # a counter pass that failed or timed out: no further passes in this run (the committed figures stand in)
+
+
+def pmc_pass(child_flags, counters, names, timeout=60):
     """One child process of this file under `rocprofv3 --pmc <counters>` (no trace domain), running nothing but one leg (`--only-step` /
     `--only-ntt`).  Returns {kernel name substring: {counter: (mean per launch, launches)}} or None when rocprofv3 is missing, the pass
     fails or a named kernel was not seen."""
@@ -83,7 +86,7 @@ def pmc_pass(child_flags, counters, names, timeout=100):
     import shutil
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe):
+    if _PMC_BROKEN[0] or not os.path.exists(exe):
         return None
     env = dict(os.environ, TMPDIR="/tmp")
     for k_ in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
@@ -93,6 +96,7 @@ def pmc_pass(child_flags, counters, names, timeout=100):
         cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + list(child_flags)
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd="/tmp")
         if r.returncode != 0:
+            _PMC_BROKEN[0] = True
             return None
         acc = {name: {c_: [0.0, 0] for c_ in counters} for name in names}
         for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
@@ -112,12 +116,13 @@ def pmc_pass(child_flags, counters, names, timeout=100):
             out[name] = {c_: (acc[name][c_][0] / acc[name][c_][1], acc[name][c_][1]) for c_ in counters}
         return out
     except (OSError, subprocess.SubprocessError, ValueError):
+        _PMC_BROKEN[0] = True
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def measure_traffic(child_flags, kernels, timeout=100):
+def measure_traffic(child_flags, kernels, timeout=60):
     """HBM bytes per launch of the named kernels, measured by THIS run: two child processes under `rocprofv3 --pmc` (FETCH_SIZE and
     WRITE_SIZE in separate passes, no trace domain in either, as the MI355X guide's HBM section prescribes).  kernels: [(name substring,
     read factor)] -- counter units are KiB; the guide's x2 on FETCH_SIZE applies to wide coalesced reads (the NTT passes), per-lane
@@ -139,7 +144,7 @@ def measure_traffic(child_flags, kernels, timeout=100):
 N_SIMD = 256 * 4  # MI355X: 256 CUs x 4 SIMDs; a SIMD issues one wave64 vector instruction per four cycles
 
 
-def measure_issue(child_flags, names, timeout=100):
+def measure_issue(child_flags, names, timeout=60):
     """Share of the chip's vector-issue slots the named kernels fill, measured by THIS run: one more `rocprofv3 --pmc` child pass with the
     SQ counters.  SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count quad-cycles summed over the waves (MI355X guide, PMC table); GRBM_GUI_ACTIVE
     is the kernel's busy cycles summed over the 8 XCDs.  issue_frac = SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 / 4): the
