@@ -94,8 +94,19 @@ def pmc_pass(child_flags, counters, names, timeout=60):
     tmp = tempfile.mkdtemp(prefix="h2pmc_", dir="/tmp")
     try:
         cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + list(child_flags)
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd="/tmp")
-        if r.returncode != 0:
+        # its own process group: a pass that overruns is ended together with the program rocprofv3 started
+        pr = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, cwd="/tmp", start_new_session=True)
+        try:
+            rcode = pr.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            import signal
+            try:
+                os.killpg(pr.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            pr.wait()
+            rcode = -1
+        if rcode != 0:
             _PMC_BROKEN[0] = True
             return None
         acc = {name: {c_: [0.0, 0] for c_ in counters} for name in names}
