@@ -895,10 +895,35 @@ void evalh_modules_free(Ctx* c) {
 
 // the generated kernel for this program on this device, or nullptr: not wanted, not compiled yet (the interpreter serves this
 // call), or not compilable (it serves every call)
+// what gen_source reads of a program, hashed: every call of evaluate_h comes here, and writing (and hashing) 20 KB of source each time to
+// find a kernel that is already loaded is ~150 us of host time per call
+static uint64_t program_fingerprint(const h2hip_graph& g, const Program& P, bool lookup) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    if (!P.ops.empty()) h = fnv1a64_raw((const char*)P.ops.data(), P.ops.size() * sizeof(DevOp), h);
+    if (g.n_constants) h = fnv1a64_raw((const char*)g.constants, (size_t)g.n_constants * 32, h);
+    if (g.n_rotations) h = fnv1a64_raw((const char*)g.rotations, (size_t)g.n_rotations * sizeof(int32_t), h);
+    const uint32_t tail[6] = {P.result.kind, P.result.a, P.result.b, P.n_slots, lookup ? 1u : 0u, (g_evalh_gen_fuse ? 1u : 0u) | (g_evalh_gen_barriers ? 2u : 0u)};
+    return fnv1a64_raw((const char*)tail, sizeof(tail), h);
+}
+static std::map<uint64_t, uint64_t> g_rtc_key_of;  // program fingerprint -> source key (under g_rtc_mu)
+
 static hipFunction_t gates_kernel_for(Ctx* c, const h2hip_graph& g, const Program& P, bool lookup = false) {
     if (g_evalh_codegen <= 0 || (P.ops.empty() && !lookup) || P.ops.size() > g_evalh_codegen_max_ops || P.n_slots > EVALH_CODEGEN_MAX_SLOTS) return nullptr;
+    const uint64_t fp = program_fingerprint(g, P, lookup);
+    {
+        std::lock_guard<std::mutex> lk(g_rtc_mu);
+        auto known = g_rtc_key_of.find(fp);
+        if (known != g_rtc_key_of.end()) {
+            auto hit = c->evalh_mods.find(known->second);
+            if (hit != c->evalh_mods.end()) return (hipFunction_t)hit->second.second;
+        }
+    }
     std::string src = gen_source(g, P, lookup);
     const uint64_t key = fnv1a64(src);
+    {
+        std::lock_guard<std::mutex> lk(g_rtc_mu);
+        g_rtc_key_of[fp] = key;
+    }
     auto hit = c->evalh_mods.find(key);
     if (hit != c->evalh_mods.end()) return (hipFunction_t)hit->second.second;
     std::shared_ptr<RtcEntry> e;
