@@ -42,6 +42,11 @@ __device__ __forceinline__ Fu addn(const Fu& a, const Fu& b) { return fu_norm(fu
 __device__ __forceinline__ Fu subn(const Fu& a, const Fu& b) { return fu_norm(fu_sub(a, b)); }
 __device__ __forceinline__ Fu mul_i(const Fu& a, const Fu& b) { return fu_mul<UF>(a, b); }
 __device__ __forceinline__ Fe out_e(const Fu& a) { return fu_mul_canon<UF>(a, fu_one_e<UF>()); }  // |a| < 16 r -> canonical E
+// One step of the fold with y (evaluation.rs: value * y + constraint) where the constraint is itself a product a * b: v y + a b with ONE
+// Montgomery reduction (the two products' columns in one accumulator, fu_mul_sub with -a) instead of two reductions and an addition.
+// Operands normalised (limbs below 2^29 in magnitude: addn / subn / mul_i / ld_i results); the magnitude of the result is below
+// (|v| |y| + |a| |b|) / 169 + 1, the sum of the two separate bounds minus one.
+__device__ __forceinline__ Fu fold_y(const Fu& v, const Fu& y, const Fu& a, const Fu& b) { return fu_mul_sub<UF>(v, y, fu_neg(a), b); }
 
 // get_rotation_idx (evaluation.rs:32-34): size is a power of two, so rem_euclid is a mask
 __device__ __forceinline__ uint32_t rot_idx(uint32_t idx, int32_t rot, int32_t rot_scale, uint32_t log_size) {
@@ -62,19 +67,20 @@ __device__ __forceinline__ void lookup_row(const LookupDev& l, const ColsDev& c,
     const Fu a_minus_s = subn(a_, s_);                                                // [64]
     Fu v = ld_i(values[idx]);                                                         // [32]
     // l_0(X) * (1 - z(X)) = 0
-    v = addn(mul_i(v, c.y), mul_i(subn(one, z), l0));                                             // [1.2 + 7.3 = 8.5]
+    v = fold_y(v, c.y, subn(one, z), l0);                                                         // [1.2 + 7.3 = 8.5]
     // l_last(X) * (z(X)^2 - z(X)) = 0
-    v = addn(mul_i(v, c.y), mul_i(subn(fu_sqr<UF>(z), z), ld_i(l.l_last[idx])));                  // [1.1 + 8.4 = 9.5]
+    v = fold_y(v, c.y, subn(fu_sqr<UF>(z), z), ld_i(l.l_last[idx]));                              // [1.1 + 8.4 = 9.5]
     // (1 - (l_last + l_blind)) * (z(wX)(a' + beta)(s' + gamma) - z(X) * table_value) = 0
     {
-        const Fu lhs = mul_i(mul_i(ld_i(l.product[r_next]), addn(a_, c.beta)), addn(s_, c.gamma));  // [32 * 33 / 169 + 1 = 7.3] -> [7.3 * 33 / 169 + 1 = 2.5]
-        const Fu rhs = mul_i(z, table_value);                                                       // [32 * 32 / 169 + 1 = 7.1]
-        v = addn(mul_i(v, c.y), mul_i(subn(lhs, rhs), l_active));                                   // [1.1] + [9.6 * 32 / 169 + 1 = 2.9] = [4]
+        // the difference of the two products with one reduction: (z(wX)(a' + beta)) (s' + gamma) - z table_value
+        const Fu zab = mul_i(ld_i(l.product[r_next]), addn(a_, c.beta));                            // [32 * 33 / 169 + 1 = 7.3]
+        const Fu diff = fu_mul_sub<UF>(zab, addn(s_, c.gamma), z, table_value);                     // [(7.3 * 33 + 32 * 32) / 169 + 1 = 8.5]
+        v = fold_y(v, c.y, diff, l_active);                                                         // [1.1] + [8.5 * 32 / 169 + 1 = 2.6] = [3.7]
     }
     // l_0(X) * (a'(X) - s'(X)) = 0
-    v = addn(mul_i(v, c.y), mul_i(a_minus_s, l0));                                                  // [1.1] + [64 * 32 / 169 + 1 = 13.2] = [14.3]
+    v = fold_y(v, c.y, a_minus_s, l0);                                                              // [1.1] + [64 * 32 / 169 + 1 = 13.2] = [14.3]
     // (1 - (l_last + l_blind)) * (a' - s') * (a'(X) - a'(w^-1 X)) = 0
-    v = addn(mul_i(v, c.y), mul_i(mul_i(a_minus_s, subn(a_, ld_i(l.pin[r_prev]))), l_active));      // [1.1] + [(64 * 64 / 169 + 1 = 25.3) * 32 / 169 + 1 = 5.8] = [6.9]
+    v = fold_y(v, c.y, mul_i(a_minus_s, subn(a_, ld_i(l.pin[r_prev]))), l_active);                  // [1.1] + [(64 * 64 / 169 + 1 = 25.3) * 32 / 169 + 1 = 5.8] = [6.9]
     values[idx] = out_e(v);
 }
 
