@@ -248,9 +248,9 @@ __global__ void __launch_bounds__(256) evalh_perm_kernel(PermDev p, ColsDev c, F
         Fu left = ld_i(zs[r_next]), right = ld_i(zs[idx]);  // [32]
         Fu diff = subn(left, right);  // (a set without columns)
         for (uint32_t j = j0; j < j1; j++) {  // both products in one walk over the set's columns: a column's value is read once
-            const Fu col = ld_i(ld_const_col(p.cols, j)[idx]);
-            const Fu lterm = addn(addn(col, mul_i(c.beta, ld_i(ld_const_col(p.cosets, j)[idx]))), c.gamma);  // [32 + 1.2 + 1 = 34.2]
-            const Fu rterm = addn(addn(col, current_delta), c.gamma);                                          // [35]
+            const Fu cg = fu_add(ld_i(ld_const_col(p.cols, j)[idx]), c.gamma);                                // column + gamma, limbs below 2^30 (not normalised)
+            const Fu lterm = fu_mul_subh<UF>(c.beta, ld_i(ld_const_col(p.cosets, j)[idx]), fu_neg(cg));        // beta * s_j + (column + gamma) in one pass   [32 + 1.2 + 1 = 34.2]
+            const Fu rterm = addn(cg, current_delta);                                                          // [35]
             current_delta = mul_i(current_delta, p.delta);                                                     // [1.1]
             if (j + 1 == j1) {
                 // the last column's two products leave as their difference, one reduction for both: [(32 * 34.2 + 32 * 35) / 169 + 1 = 14.1] for a set of

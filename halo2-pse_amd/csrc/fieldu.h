@@ -401,6 +401,12 @@ H2_HD Fu fu_mul_sub(const Fu& a, const Fu& b, const Fu& c, const Fu& d) {
     return fu_fused<U, false, true, false>(a, b, c, d, a);
 }
 
+// a*b / 2^261 - h   (h loose, |h.l| < 2^31): a product and an addend in one pass, the result normalised
+template <class U>
+H2_HD Fu fu_mul_subh(const Fu& a, const Fu& b, const Fu& h) {
+    return fu_fused<U, false, false, true>(a, b, a, a, h);
+}
+
 // a*a / 2^261 - h   (h loose, |h.l| < 2^31)
 template <class U>
 H2_HD Fu fu_sqr_sub(const Fu& a, const Fu& h) {
