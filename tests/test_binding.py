@@ -170,3 +170,23 @@ def test_patches_apply_to_the_reference(tmp_path):
     for item in called - {"evalh"}:
         src, name = (ev, item[7:]) if item.startswith("evalh::") else (lib, item)
         assert re.search(r"pub (?:unsafe )?(?:fn|struct|const|mod) %s\b" % re.escape(name), src), item
+
+
+def test_integration_appendix_is_current(tmp_path):
+    """INTEGRATION.md's appendix lists every entry point include/halo2hip.h declares, at the line it is declared on: regenerating it
+    (tools/gen_integration_appendix.py) changes nothing."""
+    import re
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    header = open(os.path.join(root, "include", "halo2hip.h")).read()
+    for name in sorted(set(re.findall(r"^(?:int|void|size_t|uint32_t|uint64_t|const char\s*\*)\s+\*?\s*(h2hip_[a-z0-9_]+)\s*\(", header, flags=re.M))):
+        assert "| `%s` |" % name in text, name
+    scratch = tmp_path / "repo"
+    for sub in ("include", "tools"):
+        shutil.copytree(os.path.join(root, sub), scratch / sub, ignore=shutil.ignore_patterns("__pycache__", "*.o", "instr_rate", "selftest", "pcie_rate", "graph_chain", "atomic_rate"))
+    shutil.copy(os.path.join(root, "INTEGRATION.md"), scratch / "INTEGRATION.md")
+    subprocess.check_call([sys.executable, str(scratch / "tools" / "gen_integration_appendix.py")])
+    assert open(scratch / "INTEGRATION.md").read() == text, "INTEGRATION.md's appendix is stale: run tools/gen_integration_appendix.py"
