@@ -566,6 +566,44 @@ def test_gpu_evaluate_h_random_graphs(h2, oracle, gates_kernel):
         assert np.array_equal(got, want), "graph %d" % i
 
 
+@pytest.mark.gpu
+def test_background_compile_switches_kernels_without_changing_values(h2, oracle):
+    """HALO2_HIP_EVALH_CODEGEN=1, the default: the first calls on a circuit the process has not seen run the interpreter while hiprtc
+    compiles the circuit's kernels on a background thread; once they are there the generated kernels take over.  Every call, before and
+    after the switch, returns the oracle's values; the switch is seen in the counters within two minutes."""
+    import time
+    L = h2.lib()
+    h2.init()
+    L.h2hip_debug_set_evalh_codegen(ctypes.c_int(1), ctypes.c_uint32(0))
+    case, vin = _random_case(oracle, 6, seed=int(time.time()) % 100000 + 31337, n_gates=5)  # a program no earlier test has compiled
+    h = DescHolder(case)
+    want = vin.copy()
+    assert oracle.lib().oracle_evaluate_h(h.byref(), want.ctypes.data_as(ctypes.c_void_p)) == 0
+    st = (ctypes.c_uint64 * 5)()
+    L.h2hip_debug_evalh_codegen_stats(st)
+    launches0, interp0, failed0 = st[2], st[3], st[1]
+    deadline = time.time() + 120
+    switched = False
+    calls = 0
+    while time.time() < deadline:
+        got = vin.copy()
+        assert L.h2hip_evaluate_h_bn254(h.byref(), got.ctypes.data_as(ctypes.c_void_p)) == 0, L.h2hip_last_error()
+        assert np.array_equal(got, want), "call %d" % calls
+        calls += 1
+        L.h2hip_debug_evalh_codegen_stats(st)
+        if st[2] > launches0:
+            switched = True
+            break
+        time.sleep(0.2)
+    assert st[1] == failed0, L.h2hip_last_error().decode()
+    assert switched, "no generated kernel after %d calls in 120 s" % calls
+    assert st[3] > interp0, "the first call cannot have found a compiled kernel"
+    for _ in range(3):  # and after the switch
+        got = vin.copy()
+        assert L.h2hip_evaluate_h_bn254(h.byref(), got.ctypes.data_as(ctypes.c_void_p)) == 0
+        assert np.array_equal(got, want)
+
+
 _DISK_CACHE = r"""
 import ctypes, json, os, sys
 import numpy as np
